@@ -1,0 +1,205 @@
+/*
+ * macaw_hip.h — C ABI of the MI355X-native (gfx950) kernels behind Macaw-LLM's
+ * multimodal forward/backward hot path.
+ *
+ * The reference (lyuchenyang/Macaw-LLM) has no FFI of its own: the hot path is
+ * eager PyTorch inside modeling.py.  Each entry point below therefore cites the
+ * reference expression (modeling.py:line, or the un-vendored torch/transformers
+ * module it calls) whose arithmetic it replaces.  The Python mirror of the
+ * reference surface (macaw_llm_amd/modeling.py) calls these through ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers
+ *     unless noted; nothing is allocated or retained; asynchronous on `stream`
+ *     (a hipStream_t passed as void*).
+ *   - return value: 0 on success, <0 on error (MK_ERR_*). Never aborts.
+ *   - dtype codes: 0 = f32, 1 = bf16, 2 = f16 (f16 only for mk_cast input).
+ *   - matrices are row-major with an explicit leading dimension (elements).
+ */
+#ifndef MACAW_HIP_H
+#define MACAW_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MK_OK 0
+#define MK_ERR_BAD_ARG (-1)
+#define MK_ERR_UNSUPPORTED (-2)
+#define MK_ERR_LAUNCH (-3)
+
+#define MK_F32 0
+#define MK_BF16 1
+#define MK_F16 2
+
+/* library identification: returns MK_ABI_VERSION */
+#define MK_ABI_VERSION 1
+int mk_abi_version(void);
+
+/* ------------------------------------------------------------------ GEMM --
+ * C[z][M,N] = act(alpha * opA(A[z]) * opB(B[z])^T + bias) + R[z] (+ C[z] if accumulate)
+ *
+ * Logical operands: A is M x K, B is N x K ("NT": both reduce over their 2nd
+ * index).  a_red_major / b_red_major = 1 means the operand is STORED with the
+ * reduction index as the row index (i.e. A stored as [K][M], B as [K][N]), so
+ * the four BLAS layouts are covered without separate transposes:
+ *   nn.Linear forward  y = x W^T        : A=x[M,K]        B=W[N,K]       (0,0)
+ *   grad input         dx = dy W        : A=dy[M,N]       B=W[N,K] as [red=N][out=K] (0,1)
+ *   grad weight        dW = dy^T x      : A=dy[M,N] as [red=M][out=N], B=x (1,1)
+ * Replaces nn.Linear (modeling.py:134-140,159-162,530,912-917), torch.matmul
+ * in LlamaAttention (modeling.py:197,215), the packed in-proj / out-proj of
+ * nn.MultiheadAttention (modeling.py:882-910) and the HF CLIP / Whisper
+ * projections (modeling.py:1073,1082,1092).
+ * Batch: grid z = z1*nb2 + z2; pointer offset = z1*s?1 + z2*s?2 (elements).
+ */
+typedef struct mk_gemm_desc {
+  const void* A;
+  const void* B;
+  void* C;
+  const void* R;    /* optional residual added after activation, same dtype as C */
+  const void* bias; /* optional, f32 or same dtype as C (see bias_dtype) */
+  int32_t M, N, K;
+  int64_t lda, ldb, ldc, ldr;
+  int32_t a_red_major, b_red_major;
+  int32_t nb1, nb2; /* batch = nb1*nb2 (>=1 each) */
+  int64_t sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
+  float alpha;
+  int32_t bias_mode;  /* 0 none, 1 per output column (n), 2 per output row (m) */
+  int32_t act;        /* 0 none, 1 gelu(erf), 2 quick_gelu (x*sigmoid(1.702x)) */
+  int32_t accumulate; /* 1: C += result */
+  int32_t dtype;      /* MK_F32 or MK_BF16: type of A,B,C,R,bias */
+} mk_gemm_desc;
+int mk_gemm(const mk_gemm_desc* d, void* stream);
+
+/* 2-D (batched) transpose out[z][c][r] = in[z][r][c]; elem_size 2 or 4. */
+int mk_transpose(const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in,
+                 int64_t ld_out, int32_t batch, int64_t s_in, int64_t s_out, int32_t elem_size,
+                 void* stream);
+
+/* ------------------------------------------------------------ norms ------
+ * RMSNorm (modeling.py:311-319): y = w * cast(x * rsqrt(mean(x^2, fp32) + eps)).
+ * Optional fused residual: h = x + res is written to h_out and normalised
+ * (LlamaDecoderLayer residual adds, modeling.py:283,289). rstd[rows] is f32.
+ */
+int mk_rmsnorm_fwd(const void* x, const void* res, const void* w, void* h_out, void* y,
+                   float* rstd, int32_t rows, int32_t cols, float eps, int32_t dtype, void* stream);
+/* dx = dres_in + rmsnorm_bwd(dy; h, rstd, w); dw_partial[nblk][cols] f32 partial
+ * column sums (reduced by mk_colsum_partials). dres_in may be NULL. */
+int mk_rmsnorm_bwd(const void* dy, const void* h, const void* w, const float* rstd,
+                   const void* dres_in, void* dx, float* dw_partial, int32_t nblk, int32_t rows,
+                   int32_t cols, int32_t dtype, void* stream);
+/* LayerNorm with bias (torch nn.LayerNorm inside HF CLIP / Whisper encoder layers). */
+int mk_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean,
+                     float* rstd, int32_t rows, int32_t cols, float eps, int32_t dtype,
+                     void* stream);
+int mk_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean,
+                     const float* rstd, const void* dres_in, void* dx, float* dw_partial,
+                     float* db_partial, int32_t nblk, int32_t rows, int32_t cols, int32_t dtype,
+                     void* stream);
+/* out[c] (+)= sum_b partial[b][c]; out dtype = `dtype`. */
+int mk_colsum_partials(const float* partial, void* out, int32_t nblk, int32_t cols,
+                       int32_t accumulate, int32_t dtype, void* stream);
+/* out[c] (+)= sum_r x[r][c] (bias gradients). ws: f32 [nblk*cols] scratch. */
+int mk_colsum(const void* x, int64_t ld, void* out, float* ws, int32_t nblk, int32_t rows,
+              int32_t cols, int32_t accumulate, int32_t dtype, void* stream);
+
+/* ----------------------------------------------------------- pointwise ---
+ * RoPE (modeling.py:76-123): x layout [B,S,H,hd] (row pitch ld between
+ * tokens), half-split rotation, cos/sin tables [max_pos, hd] in `dtype`
+ * (already cast as modeling.py:121-122 does); pos[B*S] int32 position ids;
+ * inverse=1 applies the transpose rotation (backward).
+ */
+int mk_rope(void* x, const void* cos_t, const void* sin_t, const int32_t* pos, int32_t tokens,
+            int32_t heads, int32_t hd, int64_t ld, int32_t inverse, int32_t dtype, void* stream);
+/* SwiGLU (modeling.py:140): a = silu(g) * u ; backward gives dg, du. */
+int mk_swiglu_fwd(const void* g, const void* u, void* a, int64_t n, int32_t dtype, void* stream);
+int mk_swiglu_bwd(const void* g, const void* u, const void* da, void* dg, void* du, int64_t n,
+                  int32_t dtype, void* stream);
+/* y = act(x): act 1 gelu(erf) (Whisper), 2 quick_gelu (CLIP). */
+int mk_act_fwd(const void* x, void* y, int64_t n, int32_t act, int32_t dtype, void* stream);
+/* activation backward: dx = dy * act'(x_pre); act 1 gelu(erf), 2 quick_gelu. x_pre is the
+ * pre-activation INCLUDING bias. */
+int mk_act_bwd(const void* x_pre, const void* dy, void* dx, int64_t n, int32_t act, int32_t dtype,
+               void* stream);
+/* y = a + b (b may be broadcast over rows with period `period` elements; 0 = none) */
+int mk_add(const void* a, const void* b, void* y, int64_t n, int64_t period, int32_t dtype,
+           void* stream);
+/* dtype conversion (inputs arrive as fp16 from llm_trainer.py:366-368). */
+int mk_cast(const void* in, int32_t in_dtype, void* out, int32_t out_dtype, int64_t n,
+            void* stream);
+int mk_fill(void* p, float v, int64_t n, int32_t dtype, void* stream);
+
+/* Embedding gather (modeling.py:972,979-980): out[t] = table[ids[t]]; ids int64. */
+int mk_embedding_fwd(const void* table, const int64_t* ids, void* out, int32_t tokens,
+                     int32_t dim, int64_t ld_out, int32_t vocab, int32_t dtype, void* stream);
+/* dtable[ids[t]] += dout[t], deterministic (no atomics): the first occurrence of each id
+ * sums all of its occurrences in fp32 and updates the row once. Rows equal to padding_idx
+ * (nn.Embedding padding_idx, modeling.py:358) are skipped; pass -1 for none. */
+int mk_embedding_bwd(const void* dout, int64_t ld, const int64_t* ids, void* dtable,
+                     int32_t tokens, int32_t dim, int32_t vocab, int64_t padding_idx,
+                     int32_t dtype, void* stream);
+
+/* Generic strided-window gather ("im2col") used for Conv2d patch embedding
+ * (HF CLIPVisionEmbeddings), Whisper conv1/conv2 and the project_* Conv1d
+ * (modeling.py:919-924): out[(b,j)][c*kw + t] = x[b*sb + c*sc + (j*stride + t - pad)*st]
+ * (zero outside [0,T)), rows padded with zeros up to ld_out. 2-D patches are
+ * expressed by the caller as two nested calls or by mk_patchify. */
+int mk_im2col1d(const void* x, void* out, int32_t B, int32_t C, int32_t T, int32_t kw,
+                int32_t stride, int32_t pad, int32_t Lout, int64_t sb, int64_t sc, int64_t st,
+                int64_t ld_out, int32_t dtype, void* stream);
+/* adjoint of mk_im2col1d (gather form, no atomics): dx = col2im(dcols). */
+int mk_col2im1d(const void* dcols, void* dx, int32_t B, int32_t C, int32_t T, int32_t kw,
+                int32_t stride, int32_t pad, int32_t Lout, int64_t sb, int64_t sc, int64_t st,
+                int64_t ld_cols, int32_t dtype, void* stream);
+/* Non-overlapping 2-D patches: out[(b,py,px)][c*P*P + dy*P + dx] = img[b][c][py*P+dy][px*P+dx] */
+int mk_patchify(const void* img, void* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t P,
+                int64_t ld_out, int32_t dtype, void* stream);
+int mk_unpatchify(const void* dcols, void* dimg, int32_t B, int32_t C, int32_t H, int32_t W,
+                  int32_t P, int64_t ld_cols, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------- softmax ---
+ * Row softmax over scores[z][q][k] with the reference's masking semantics
+ * (modeling.py:205-214): causal (k > q + (Lk-Lq) masked) and/or key padding
+ * mask kmask[b][Lk] (int32, 0 = masked); masked logits become finfo.min and
+ * softmax runs in fp32 then casts.  Optional dropout on the probabilities
+ * (nn.MultiheadAttention dropout=0.1, modeling.py:879): keep iff
+ * hash(seed, element index) < keep_threshold, kept values scaled by
+ * 1/(1-p).  In-place (probs may alias scores).  heads = rows of z per batch
+ * element (kmask index = z / heads).
+ */
+int mk_softmax_fwd(const void* scores, void* probs, void* probs_dropped /* NULL if p == 0 */,
+                   const int32_t* kmask, int32_t nz, int32_t heads, int32_t Lq, int32_t Lk,
+                   int64_t ld, int32_t causal, float dropout_p, uint64_t seed, int32_t dtype,
+                   void* stream);
+/* dscores = (P .* (g - rowsum(g .* P))) * scale, g = dP_dropped .* keep/(1-p); in place on
+ * dprobs.  probs are the PRE-dropout probabilities; the dropout mask is regenerated from
+ * (seed, element index). */
+int mk_softmax_bwd(const void* probs, void* dprobs, int32_t nz, int32_t Lq, int32_t Lk,
+                   int64_t ld, float scale, float dropout_p, uint64_t seed, int32_t dtype,
+                   void* stream);
+
+/* Shifted cross-entropy (modeling.py:600-610). The caller passes labels already shifted
+ * (row r predicts labels[r]; -100 = ignore).  row_loss[r] = lse_r - logit[r][label] (0 when
+ * ignored), row_lse[r] kept for backward, loss_sum_cnt = {sum of row losses, number of valid
+ * rows} (f32[2], reduced deterministically on device; loss = [0]/[1]). */
+int mk_cross_entropy(const void* logits, const int64_t* labels, float* row_loss, float* row_lse,
+                     float* loss_sum_cnt, int32_t rows, int32_t V, int64_t ld, int32_t dtype,
+                     void* stream);
+/* dlogits[r][c] = (softmax(logits[r])[c] - [c == label]) * grad_scale / n_valid, zero for
+ * ignored rows and for pad columns c in [V, ld).  dlogits may alias logits. */
+int mk_cross_entropy_bwd(const void* logits, void* dlogits, const int64_t* labels,
+                         const float* row_lse, const float* loss_sum_cnt, float grad_scale,
+                         int32_t rows, int32_t V, int64_t ld, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------ optimizer --
+ * Fused AdamW over a flat shard (replaces DeepSpeed CPU-offloaded Adam,
+ * configs/deepspeed_config.json:2-13): fp32 master/m/v, `dtype` grads and
+ * model weights.  grad_scale multiplies grads first (loss scaling / 1/world). */
+int mk_adamw(void* param, float* master, float* m, float* v, const void* grad, int64_t n,
+             float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+             float grad_scale, int32_t dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MACAW_HIP_H */

@@ -1,0 +1,127 @@
+// Shared device helpers for the macaw_hip kernels (gfx950 / CDNA4 only).
+// Wave size is hard-coded to 64 (cdna_hip_programming.md §1).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MK_WAVE 64
+
+// Error codes returned through the C ABI (include/macaw_hip.h).
+#define MK_OK 0
+#define MK_ERR_BAD_ARG (-1)
+#define MK_ERR_UNSUPPORTED (-2)
+#define MK_ERR_LAUNCH (-3)
+
+// dtype codes of the C ABI
+#define MK_F32 0
+#define MK_BF16 1
+#define MK_F16 2
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define MK_DEV __device__ __forceinline__
+
+static inline int mk_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MK_OK : MK_ERR_LAUNCH;
+}
+
+// ---- scalar load/store as float regardless of storage type -------------
+template <typename T> MK_DEV float to_f32(T v);
+template <> MK_DEV float to_f32<float>(float v) { return v; }
+template <> MK_DEV float to_f32<bf16>(bf16 v) { return (float)v; }
+template <> MK_DEV float to_f32<_Float16>(_Float16 v) { return (float)v; }
+template <typename T> MK_DEV T from_f32(float v);
+template <> MK_DEV float from_f32<float>(float v) { return v; }
+template <> MK_DEV bf16 from_f32<bf16>(float v) { return (bf16)v; }  // RNE (v_cvt_pk_bf16_f32)
+template <> MK_DEV _Float16 from_f32<_Float16>(float v) { return (_Float16)v; }
+
+// Vector-of-VEC access: VEC elements of T moved as one 16-byte (bf16x8) or
+// 16-byte (float4) transaction.  VecIO<T>::N elements per 16 B.
+template <typename T> struct VecIO;
+template <> struct VecIO<float> {
+  static constexpr int N = 4;
+  MK_DEV static void load(const float* p, float (&o)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+  MK_DEV static void store(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+};
+template <> struct VecIO<bf16> {
+  static constexpr int N = 8;
+  MK_DEV static void load(const bf16* p, float (&o)[8]) {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
+  MK_DEV static void store(bf16* p, const float (&o)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)o[i];
+    *reinterpret_cast<bf16x8*>(p) = v;
+  }
+};
+
+// ---- wave / block reductions -------------------------------------------
+MK_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+MK_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// Block-wide sum; `red` is LDS scratch of >= 16 floats. All threads get the result.
+template <int NT> MK_DEV float block_sum(float v, float* red) {
+  constexpr int NW = NT / 64;
+  v = wave_sum(v);
+  if constexpr (NW == 1) return v;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) r += red[i];
+  return r;
+}
+template <int NT> MK_DEV float block_max(float v, float* red) {
+  constexpr int NW = NT / 64;
+  v = wave_max(v);
+  if constexpr (NW == 1) return v;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) r = fmaxf(r, red[i]);
+  return r;
+}
+
+// Counter-based RNG for attention dropout: one 32-bit hash per (seed, index).
+// Keep/drop is a pure function of (seed, linear element index) so forward and
+// backward kernels regenerate the identical mask without storing it.
+MK_DEV uint32_t mk_hash32(uint64_t seed, uint64_t idx) {
+  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27; z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 16);
+}
+MK_DEV bool mk_keep(uint64_t seed, uint64_t idx, uint32_t keep_threshold) {
+  // keep iff hash < keep_threshold, keep_threshold = (1-p) * 2^32 (saturated)
+  return mk_hash32(seed, idx) < keep_threshold;
+}
+
+static inline int mk_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

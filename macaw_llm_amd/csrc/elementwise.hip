@@ -1,0 +1,431 @@
+// HBM-bound pointwise / gather kernels: RoPE, SwiGLU, activations, add, cast,
+// fill, embedding gather + deterministic scatter, im2col / col2im, patchify.
+// All use 16-byte vector access on the fast path (cdna_hip_programming.md G13)
+// and grid-stride loops capped at 256 CUs x 8 blocks.
+#include "common.h"
+#include "../../include/macaw_hip.h"
+
+namespace {
+
+template <typename T> MK_DEV float rnd(float v) { return to_f32<T>(from_f32<T>(v)); }
+
+inline int ew_grid(long work_items) {
+  long b = (work_items + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------- RoPE --
+// x[t][h][hd], token pitch ld.  Half-split rotation (modeling.py:76-91):
+//   out[j]      = x[j]*cos[j]     - x[j+half]*sin[j]
+//   out[j+half] = x[j+half]*cos[j] + x[j]*sin[j]        (cos[j] == cos[j+half])
+// with each product and the sum rounded to T, as the eager bf16 reference does.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void rope_kernel(T* x, const T* cos_t, const T* sin_t,
+                                                   const int32_t* pos, int tokens, int heads,
+                                                   int hd, long ld, float sgn) {
+  constexpr int N = VEC ? VecIO<T>::N : 1;
+  const int half = hd / 2;
+  const int cph = half / N;  // chunks per head-half
+  const long total = (long)tokens * heads * cph;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % cph);
+    const long th = idx / cph;
+    const int h = (int)(th % heads);
+    const long t = th / heads;
+    const int p = pos[t];
+    T* xp = x + t * ld + (long)h * hd + c * N;
+    const T* cp = cos_t + (long)p * hd + c * N;
+    const T* sp = sin_t + (long)p * hd + c * N;
+    float a[N], b[N], cs[N], sn[N];
+    if constexpr (VEC) {
+      VecIO<T>::load(xp, a); VecIO<T>::load(xp + half, b);
+      VecIO<T>::load(cp, cs); VecIO<T>::load(sp, sn);
+    } else {
+      a[0] = to_f32<T>(xp[0]); b[0] = to_f32<T>(xp[half]);
+      cs[0] = to_f32<T>(cp[0]); sn[0] = to_f32<T>(sp[0]);
+    }
+    float o1[N], o2[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const float s = sgn * sn[i];
+      o1[i] = rnd<T>(rnd<T>(a[i] * cs[i]) + rnd<T>(-b[i] * s));
+      o2[i] = rnd<T>(rnd<T>(b[i] * cs[i]) + rnd<T>(a[i] * s));
+    }
+    if constexpr (VEC) { VecIO<T>::store(xp, o1); VecIO<T>::store(xp + half, o2); }
+    else { xp[0] = from_f32<T>(o1[0]); xp[half] = from_f32<T>(o2[0]); }
+  }
+}
+
+// ----------------------------------------------------------------- SwiGLU --
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* g, const T* u, T* a, long n) {
+  constexpr int N = VecIO<T>::N;
+  const long nch = n / N;
+  for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long)gridDim.x * 256) {
+    float gv[N], uv[N], o[N];
+    VecIO<T>::load(g + c * N, gv); VecIO<T>::load(u + c * N, uv);
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = rnd<T>(gv[i] / (1.f + __expf(-gv[i]))) * uv[i];
+    VecIO<T>::store(a + c * N, o);
+  }
+  for (long i = nch * N + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gv = to_f32<T>(g[i]);
+    a[i] = from_f32<T>(rnd<T>(gv / (1.f + __expf(-gv))) * to_f32<T>(u[i]));
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* g, const T* u, const T* da,
+                                                         T* dg, T* du, long n) {
+  constexpr int N = VecIO<T>::N;
+  const long nch = n / N;
+  for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long)gridDim.x * 256) {
+    float gv[N], uv[N], dv[N], og[N], ou[N];
+    VecIO<T>::load(g + c * N, gv); VecIO<T>::load(u + c * N, uv); VecIO<T>::load(da + c * N, dv);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const float s = 1.f / (1.f + __expf(-gv[i]));
+      ou[i] = dv[i] * gv[i] * s;
+      og[i] = dv[i] * uv[i] * s * (1.f + gv[i] * (1.f - s));
+    }
+    VecIO<T>::store(dg + c * N, og); VecIO<T>::store(du + c * N, ou);
+  }
+  for (long i = nch * N + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gv = to_f32<T>(g[i]), uv = to_f32<T>(u[i]), dv = to_f32<T>(da[i]);
+    const float s = 1.f / (1.f + __expf(-gv));
+    du[i] = from_f32<T>(dv * gv * s);
+    dg[i] = from_f32<T>(dv * uv * s * (1.f + gv * (1.f - s)));
+  }
+}
+
+// ------------------------------------------------------------ activations --
+MK_DEV float act_fwd(float v, int act) {
+  if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  if (act == 2) return v / (1.0f + __expf(-1.702f * v));
+  return v;
+}
+MK_DEV float act_grad(float v, int act) {
+  if (act == 1) {
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+    return cdf + v * pdf;
+  }
+  if (act == 2) {
+    const float s = 1.f / (1.f + __expf(-1.702f * v));
+    return s * (1.f + 1.702f * v * (1.f - s));
+  }
+  return 1.f;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const T* x, T* y, long n, int act) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    y[i] = from_f32<T>(act_fwd(to_f32<T>(x[i]), act));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* x, const T* dy, T* dx, long n,
+                                                      int act) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    dx[i] = from_f32<T>(to_f32<T>(dy[i]) * act_grad(to_f32<T>(x[i]), act));
+}
+
+// -------------------------------------------------------- add / cast / fill --
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* a, const T* b, T* y, long n,
+                                                  long period) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long j = period > 0 ? i % period : i;
+    y[i] = from_f32<T>(to_f32<T>(a[i]) + to_f32<T>(b[j]));
+  }
+}
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* in, TO* out, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    out[i] = from_f32<TO>(to_f32<TI>(in[i]));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fill_kernel(T* p, float v, long n) {
+  const T tv = from_f32<T>(v);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = tv;
+}
+
+// -------------------------------------------------------------- embedding --
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const T* table, const int64_t* ids,
+                                                            T* out, int dim, long ld_out,
+                                                            int vocab) {
+  const long t = blockIdx.x;
+  long id = ids[t];
+  if (id < 0 || id >= vocab) id = 0;  // host validates; never fault
+  const T* src = table + id * dim;
+  T* dst = out + t * ld_out;
+  constexpr int N = VecIO<T>::N;
+  if ((dim % N) == 0 && (ld_out % N) == 0) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (int c = threadIdx.x; c < dim / N; c += 256) d4[c] = s4[c];
+  } else {
+    for (int c = threadIdx.x; c < dim; c += 256) dst[c] = src[c];
+  }
+}
+// Deterministic scatter-add without atomics: the block of the FIRST occurrence
+// of a token id sums every later occurrence (fp32) and updates the row once.
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const T* dout, long ld,
+                                                            const int64_t* ids, T* dtable,
+                                                            int tokens, int dim, int vocab,
+                                                            long padding_idx) {
+  __shared__ int dup;
+  const int t = blockIdx.x;
+  const long id = ids[t];
+  if (id < 0 || id >= vocab || id == padding_idx) return;
+  if (threadIdx.x == 0) dup = 0;
+  __syncthreads();
+  for (int j = threadIdx.x; j < t; j += 256)
+    if (ids[j] == id) dup = 1;
+  __syncthreads();
+  if (dup) return;
+  for (int c0 = 0; c0 < dim; c0 += 256) {
+    const int c = c0 + threadIdx.x;
+    if (c >= dim) continue;
+    float acc = 0.f;
+    for (int j = t; j < tokens; ++j)
+      if (ids[j] == id) acc += to_f32<T>(dout[(long)j * ld + c]);
+    T* dp = dtable + id * dim + c;
+    *dp = from_f32<T>(to_f32<T>(*dp) + acc);
+  }
+}
+
+// --------------------------------------------------------- im2col / col2im --
+template <typename T>
+__global__ __launch_bounds__(256) void im2col1d_kernel(const T* x, T* out, int B, int C, int Tn,
+                                                       int kw, int stride, int pad, int Lout,
+                                                       long sb, long sc, long st, long ld_out) {
+  const long total = (long)B * Lout * ld_out;
+  const int K = C * kw;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int col = (int)(i % ld_out);
+    const long row = i / ld_out;
+    T v = from_f32<T>(0.f);
+    if (col < K) {
+      const int c = col / kw, t = col - c * kw;
+      const int j = (int)(row % Lout);
+      const long b = row / Lout;
+      const int tau = j * stride + t - pad;
+      if (tau >= 0 && tau < Tn) v = x[b * sb + c * sc + tau * st];
+    }
+    out[i] = v;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void col2im1d_kernel(const T* dcols, T* dx, int B, int C, int Tn,
+                                                       int kw, int stride, int pad, int Lout,
+                                                       long sb, long sc, long st, long ld_cols) {
+  const long total = (long)B * C * Tn;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    // enumerate in (b, tau, c) order when channels are contiguous (sc == 1), else (b, c, tau)
+    int c, tau; long b;
+    if (sc == 1) { c = (int)(i % C); const long r = i / C; tau = (int)(r % Tn); b = r / Tn; }
+    else { tau = (int)(i % Tn); const long r = i / Tn; c = (int)(r % C); b = r / C; }
+    const int p = tau + pad;
+    int jlo = (p - kw + 1 + stride - 1) / stride;  // ceil((p-kw+1)/stride) for p-kw+1 >= 0
+    if (p - kw + 1 < 0) jlo = 0;
+    int jhi = p / stride;
+    if (jhi > Lout - 1) jhi = Lout - 1;
+    float acc = 0.f;
+    for (int j = jlo; j <= jhi; ++j) {
+      const int t = p - j * stride;
+      if (t >= 0 && t < kw) acc += to_f32<T>(dcols[((long)b * Lout + j) * ld_cols + c * kw + t]);
+    }
+    dx[b * sb + c * sc + tau * st] = from_f32<T>(acc);
+  }
+}
+template <typename T, bool FWD>
+__global__ __launch_bounds__(256) void patchify_kernel(const T* img, T* cols, int B, int C, int H,
+                                                       int W, int P, long ld) {
+  const int gy = H / P, gx = W / P;
+  const int K = C * P * P;
+  const long total = (long)B * gy * gx * (FWD ? ld : K);
+  const int rowlen = FWD ? (int)ld : K;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int col = (int)(i % rowlen);
+    const long row = i / rowlen;
+    if (col >= K) { if (FWD) cols[row * ld + col] = from_f32<T>(0.f); continue; }
+    const int c = col / (P * P), rem = col - c * P * P, dy = rem / P, dx = rem - dy * P;
+    const int px = (int)(row % gx);
+    const long r2 = row / gx;
+    const int py = (int)(r2 % gy);
+    const long b = r2 / gy;
+    const long ii = ((b * C + c) * H + py * P + dy) * W + px * P + dx;
+    if (FWD) cols[row * ld + col] = img[ii];
+    else const_cast<T*>(img)[ii] = cols[row * ld + col];
+  }
+}
+
+}  // namespace
+
+#define MK_ST reinterpret_cast<hipStream_t>(stream)
+#define MK_DISPATCH_T(dtype, CALL)                     \
+  do {                                                 \
+    if ((dtype) == MK_BF16) { using T = bf16; CALL; }  \
+    else if ((dtype) == MK_F32) { using T = float; CALL; } \
+    else return MK_ERR_UNSUPPORTED;                    \
+  } while (0)
+
+extern "C" int mk_rope(void* x, const void* cos_t, const void* sin_t, const int32_t* pos,
+                       int32_t tokens, int32_t heads, int32_t hd, int64_t ld, int32_t inverse,
+                       int32_t dtype, void* stream) {
+  if (!x || !cos_t || !sin_t || !pos || tokens <= 0 || heads <= 0 || hd <= 0 || (hd & 1))
+    return MK_ERR_BAD_ARG;
+  const float sgn = inverse ? -1.f : 1.f;
+  const int half = hd / 2;
+  MK_DISPATCH_T(dtype, {
+    constexpr int N = VecIO<T>::N;
+    const bool vec = (half % N == 0) && (ld % N == 0) &&
+                     ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(cos_t) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(sin_t) & 15) == 0);
+    if (vec) {
+      const long total = (long)tokens * heads * (half / N);
+      hipLaunchKernelGGL((rope_kernel<T, true>), dim3(ew_grid(total)), dim3(256), 0, MK_ST, (T*)x,
+                         (const T*)cos_t, (const T*)sin_t, pos, tokens, heads, hd, (long)ld, sgn);
+    } else {
+      const long total = (long)tokens * heads * half;
+      hipLaunchKernelGGL((rope_kernel<T, false>), dim3(ew_grid(total)), dim3(256), 0, MK_ST, (T*)x,
+                         (const T*)cos_t, (const T*)sin_t, pos, tokens, heads, hd, (long)ld, sgn);
+    }
+  });
+  return mk_check_launch();
+}
+
+extern "C" int mk_swiglu_fwd(const void* g, const void* u, void* a, int64_t n, int32_t dtype,
+                             void* stream) {
+  if (!g || !u || !a || n <= 0) return MK_ERR_BAD_ARG;
+  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((swiglu_fwd_kernel<T>),
+                                          dim3(ew_grid(n / VecIO<T>::N + 1)), dim3(256), 0, MK_ST,
+                                          (const T*)g, (const T*)u, (T*)a, (long)n));
+  return mk_check_launch();
+}
+extern "C" int mk_swiglu_bwd(const void* g, const void* u, const void* da, void* dg, void* du,
+                             int64_t n, int32_t dtype, void* stream) {
+  if (!g || !u || !da || !dg || !du || n <= 0) return MK_ERR_BAD_ARG;
+  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((swiglu_bwd_kernel<T>),
+                                          dim3(ew_grid(n / VecIO<T>::N + 1)), dim3(256), 0, MK_ST,
+                                          (const T*)g, (const T*)u, (const T*)da, (T*)dg, (T*)du,
+                                          (long)n));
+  return mk_check_launch();
+}
+extern "C" int mk_act_fwd(const void* x, void* y, int64_t n, int32_t act, int32_t dtype,
+                          void* stream) {
+  if (!x || !y || n <= 0) return MK_ERR_BAD_ARG;
+  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((act_fwd_kernel<T>), dim3(ew_grid(n)), dim3(256), 0,
+                                          MK_ST, (const T*)x, (T*)y, (long)n, act));
+  return mk_check_launch();
+}
+extern "C" int mk_act_bwd(const void* x_pre, const void* dy, void* dx, int64_t n, int32_t act,
+                          int32_t dtype, void* stream) {
+  if (!x_pre || !dy || !dx || n <= 0) return MK_ERR_BAD_ARG;
+  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(ew_grid(n)), dim3(256), 0,
+                                          MK_ST, (const T*)x_pre, (const T*)dy, (T*)dx, (long)n,
+                                          act));
+  return mk_check_launch();
+}
+extern "C" int mk_add(const void* a, const void* b, void* y, int64_t n, int64_t period,
+                      int32_t dtype, void* stream) {
+  if (!a || !b || !y || n <= 0) return MK_ERR_BAD_ARG;
+  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((add_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, MK_ST,
+                                          (const T*)a, (const T*)b, (T*)y, (long)n, (long)period));
+  return mk_check_launch();
+}
+extern "C" int mk_fill(void* p, float v, int64_t n, int32_t dtype, void* stream) {
+  if (!p || n <= 0) return MK_ERR_BAD_ARG;
+  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((fill_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, MK_ST,
+                                          (T*)p, v, (long)n));
+  return mk_check_launch();
+}
+
+namespace {
+template <typename TI>
+int cast_from(const void* in, void* out, int32_t out_dtype, long n, hipStream_t st) {
+  dim3 grid(ew_grid(n)), block(256);
+  if (out_dtype == MK_F32)
+    hipLaunchKernelGGL((cast_kernel<TI, float>), grid, block, 0, st, (const TI*)in, (float*)out, n);
+  else if (out_dtype == MK_BF16)
+    hipLaunchKernelGGL((cast_kernel<TI, bf16>), grid, block, 0, st, (const TI*)in, (bf16*)out, n);
+  else if (out_dtype == MK_F16)
+    hipLaunchKernelGGL((cast_kernel<TI, _Float16>), grid, block, 0, st, (const TI*)in,
+                       (_Float16*)out, n);
+  else return MK_ERR_UNSUPPORTED;
+  return mk_check_launch();
+}
+}  // namespace
+extern "C" int mk_cast(const void* in, int32_t in_dtype, void* out, int32_t out_dtype, int64_t n,
+                       void* stream) {
+  if (!in || !out || n <= 0) return MK_ERR_BAD_ARG;
+  if (in_dtype == MK_F32) return cast_from<float>(in, out, out_dtype, n, MK_ST);
+  if (in_dtype == MK_BF16) return cast_from<bf16>(in, out, out_dtype, n, MK_ST);
+  if (in_dtype == MK_F16) return cast_from<_Float16>(in, out, out_dtype, n, MK_ST);
+  return MK_ERR_UNSUPPORTED;
+}
+
+extern "C" int mk_embedding_fwd(const void* table, const int64_t* ids, void* out, int32_t tokens,
+                                int32_t dim, int64_t ld_out, int32_t vocab, int32_t dtype,
+                                void* stream) {
+  if (!table || !ids || !out || tokens <= 0 || dim <= 0 || vocab <= 0) return MK_ERR_BAD_ARG;
+  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((embedding_fwd_kernel<T>), dim3(tokens), dim3(256), 0,
+                                          MK_ST, (const T*)table, ids, (T*)out, dim, (long)ld_out,
+                                          vocab));
+  return mk_check_launch();
+}
+extern "C" int mk_embedding_bwd(const void* dout, int64_t ld, const int64_t* ids, void* dtable,
+                                int32_t tokens, int32_t dim, int32_t vocab, int64_t padding_idx,
+                                int32_t dtype, void* stream) {
+  if (!dout || !ids || !dtable || tokens <= 0 || dim <= 0 || vocab <= 0) return MK_ERR_BAD_ARG;
+  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((embedding_bwd_kernel<T>), dim3(tokens), dim3(256), 0,
+                                          MK_ST, (const T*)dout, (long)ld, ids, (T*)dtable, tokens,
+                                          dim, vocab, (long)padding_idx));
+  return mk_check_launch();
+}
+
+extern "C" int mk_im2col1d(const void* x, void* out, int32_t B, int32_t C, int32_t T_, int32_t kw,
+                           int32_t stride, int32_t pad, int32_t Lout, int64_t sb, int64_t sc,
+                           int64_t st, int64_t ld_out, int32_t dtype, void* stream) {
+  if (!x || !out || B <= 0 || C <= 0 || T_ <= 0 || kw <= 0 || stride <= 0 || Lout <= 0 ||
+      ld_out < (int64_t)C * kw)
+    return MK_ERR_BAD_ARG;
+  const long total = (long)B * Lout * ld_out;
+  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((im2col1d_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
+                                          MK_ST, (const T*)x, (T*)out, B, C, T_, kw, stride, pad,
+                                          Lout, (long)sb, (long)sc, (long)st, (long)ld_out));
+  return mk_check_launch();
+}
+extern "C" int mk_col2im1d(const void* dcols, void* dx, int32_t B, int32_t C, int32_t T_,
+                           int32_t kw, int32_t stride, int32_t pad, int32_t Lout, int64_t sb,
+                           int64_t sc, int64_t st, int64_t ld_cols, int32_t dtype, void* stream) {
+  if (!dcols || !dx || B <= 0 || C <= 0 || T_ <= 0 || kw <= 0 || stride <= 0 || Lout <= 0)
+    return MK_ERR_BAD_ARG;
+  const long total = (long)B * C * T_;
+  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((col2im1d_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
+                                          MK_ST, (const T*)dcols, (T*)dx, B, C, T_, kw, stride, pad,
+                                          Lout, (long)sb, (long)sc, (long)st, (long)ld_cols));
+  return mk_check_launch();
+}
+extern "C" int mk_patchify(const void* img, void* out, int32_t B, int32_t C, int32_t H, int32_t W,
+                           int32_t P, int64_t ld_out, int32_t dtype, void* stream) {
+  if (!img || !out || B <= 0 || C <= 0 || P <= 0 || H % P || W % P || ld_out < (int64_t)C * P * P)
+    return MK_ERR_BAD_ARG;
+  const long total = (long)B * (H / P) * (W / P) * ld_out;
+  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((patchify_kernel<T, true>), dim3(ew_grid(total)),
+                                          dim3(256), 0, MK_ST, (const T*)img, (T*)out, B, C, H, W,
+                                          P, (long)ld_out));
+  return mk_check_launch();
+}
+extern "C" int mk_unpatchify(const void* dcols, void* dimg, int32_t B, int32_t C, int32_t H,
+                             int32_t W, int32_t P, int64_t ld_cols, int32_t dtype, void* stream) {
+  if (!dcols || !dimg || B <= 0 || C <= 0 || P <= 0 || H % P || W % P) return MK_ERR_BAD_ARG;
+  const long total = (long)B * (H / P) * (W / P) * C * P * P;
+  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((patchify_kernel<T, false>), dim3(ew_grid(total)),
+                                          dim3(256), 0, MK_ST, (const T*)dimg, (T*)dcols, B, C, H,
+                                          W, P, (long)ld_cols));
+  return mk_check_launch();
+}

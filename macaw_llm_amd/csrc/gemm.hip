@@ -1,0 +1,479 @@
+// GEMM kernels for gfx950 (MI355X).
+//
+//   bf16 path : 128x128x64 block tile, 4 waves (2x2), each wave 64x64 through
+//               v_mfma_f32_32x32x16_bf16 (2x2 fragments, 64 accumulator VGPRs).
+//               Operand tiles are staged global -> registers -> LDS (double
+//               buffered, one barrier per K-tile; the next tile's global loads
+//               are issued before the MFMA block so HBM latency hides under
+//               compute).  Two LDS images, chosen per operand:
+//                 K-major  (reduction index contiguous, e.g. x[M,K], W[N,K]):
+//                   [128 rows][64 k] with the 16-B chunk index XOR-swizzled by
+//                   (row>>1)&7 -> conflict-free ds_read_b128 fragment reads.
+//                 red-major (operand stored [K][rows], e.g. W in dx = dy.W, and
+//                   both operands of dW = dy^T.x): [64 k][128 rows] with the
+//                   chunk index XOR 4*(k&3); fragments come out of LDS through
+//                   ds_read_b64_tr_b16 (hardware transpose read), so no
+//                   separate transpose pass over HBM is ever needed.
+//               MFMA operand order is (N-fragment, M-fragment) so each lane ends
+//               up with 4 consecutive n for one m: 8-byte row-major C stores.
+//   f32 path  : exact-f32 v_mfma_f32_16x16x4_f32, 64x64x16 tile; parity mode
+//               (fp32 end-to-end vs the fp32 oracle) and on-device cross-check.
+//
+// Replaces: nn.Linear / torch.matmul call sites listed in include/macaw_hip.h.
+#include "common.h"
+#include "../../include/macaw_hip.h"
+
+namespace {
+
+struct GemmArgs {
+  const void* A; const void* B; void* C; const void* R; const void* bias;
+  int M, N, K;
+  long lda, ldb, ldc, ldr;
+  int nb2;
+  long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
+  float alpha;
+  int bias_mode, act, accumulate;
+  int tiles_m, tiles_n;
+  int a_vec, b_vec;  // 1: 16-byte aligned vector loads allowed
+  int c_vec;         // 1: vector C/R access allowed
+};
+
+MK_DEV float apply_act(float v, int act) {
+  if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  if (act == 2) return v / (1.0f + __expf(-1.702f * v));
+  return v;
+}
+
+// XCD-aware + grouped tile order (cdna_hip_programming.md T1, bijective form).
+MK_DEV void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  const int xcd = bid & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(tiles_m - first_m, GROUP_M);
+  const int in_g = wg - group * per_group;
+  tm = first_m + in_g % gsize;
+  tn = in_g / gsize;
+}
+
+// ------------------------------------------------------------------ bf16 --
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
+
+// 8 bf16 from global with zero fill; `valid` = number of leading valid elements.
+// Slow path (edge tiles / unaligned operands): kept out of line so the hot loop
+// stays small.
+__device__ __attribute__((noinline)) uint4 load_chunk_slow(const bf16* p, int valid, bool vec) {
+  if (valid >= 8 && vec) return *reinterpret_cast<const uint4*>(p);
+  const unsigned short* s = reinterpret_cast<const unsigned short*>(p);
+  unsigned e0 = valid > 0 ? s[0] : 0, e1 = valid > 1 ? s[1] : 0, e2 = valid > 2 ? s[2] : 0,
+           e3 = valid > 3 ? s[3] : 0, e4 = valid > 4 ? s[4] : 0, e5 = valid > 5 ? s[5] : 0,
+           e6 = valid > 6 ? s[6] : 0, e7 = valid > 7 ? s[7] : 0;
+  return make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
+}
+
+// Stage one 128(rows) x 64(k) operand tile: global -> regs.
+template <bool RED_MAJOR>
+MK_DEV void tile_load(const bf16* base, long ld, int row0, int k0, int R, int K, bool vec,
+                      uint4 (&r)[4]) {
+  const int tid = threadIdx.x;
+  const bool interior = vec && (row0 + 128 <= R) && (k0 + BK <= K);  // block-uniform
+  if (interior) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      if constexpr (!RED_MAJOR) {
+        const int row = c >> 3, kc = c & 7;
+        r[i] = *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * ld + k0 + kc * 8);
+      } else {
+        const int kr = c >> 4, mc = c & 15;
+        r[i] = *reinterpret_cast<const uint4*>(base + (long)(k0 + kr) * ld + row0 + mc * 8);
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      uint4 v;
+      if constexpr (!RED_MAJOR) {
+        const int row = c >> 3, kc = c & 7;
+        const int gr = row0 + row, gk = k0 + kc * 8;
+        const int valid = (gr < R) ? min(max(K - gk, 0), 8) : 0;
+        v = load_chunk_slow(base + (long)gr * ld + gk, valid, vec);
+      } else {
+        const int kr = c >> 4, mc = c & 15;
+        const int gk = k0 + kr, gr = row0 + mc * 8;
+        const int valid = (gk < K) ? min(max(R - gr, 0), 8) : 0;
+        v = load_chunk_slow(base + (long)gk * ld + gr, valid, vec);
+      }
+      if (i == 0) r[0] = v; else if (i == 1) r[1] = v; else if (i == 2) r[2] = v; else r[3] = v;
+    }
+  }
+}
+// regs -> LDS image (swizzled).
+template <bool RED_MAJOR>
+MK_DEV void tile_store(char* lds, const uint4 (&r)[4]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    int off;
+    if constexpr (!RED_MAJOR) {
+      const int row = c >> 3, kc = c & 7;
+      off = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+    } else {
+      const int kr = c >> 4, mc = c & 15;
+      off = kr * 256 + ((mc ^ (4 * (kr & 3))) << 4);
+    }
+    *reinterpret_cast<uint4*>(lds + off) = r[i];
+  }
+}
+// Fragment for v_mfma_f32_32x32x16_bf16: lane l holds row (l&31), k = 8*(l>>5)+j.
+template <bool RED_MAJOR>
+MK_DEV bf16x8 frag_load(const char* lds, int row_base, int ks) {
+  const int l = threadIdx.x & 63;
+  if constexpr (!RED_MAJOR) {
+    const int row = row_base + (l & 31);
+    const int kc = ks * 2 + (l >> 5);
+    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+  } else {
+    // two transpose reads of a [4 k][16 rows] block each
+    const int li = l & 15;
+    const int col = row_base + 16 * ((l >> 4) & 1) + 4 * (li & 3);
+    const int kr0 = ks * 16 + 8 * (l >> 5) + (li >> 2);
+    bf16x8 out;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int kr = kr0 + 4 * r;
+      const int off = kr * 256 + (((col >> 3) ^ (4 * (kr & 3))) << 4) + ((col & 7) << 1);
+      bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4*)(lds + off));
+      out[4 * r + 0] = t[0]; out[4 * r + 1] = t[1]; out[4 * r + 2] = t[2]; out[4 * r + 3] = t[3];
+    }
+    return out;
+  }
+}
+
+template <bool A_RED, bool B_RED>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tm, tn;
+  tile_coords(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
+  const int z = blockIdx.z, z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+  const bf16* A = reinterpret_cast<const bf16*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
+  const bf16* B = reinterpret_cast<const bf16*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
+  bf16* C = reinterpret_cast<bf16*>(g.C) + z1 * g.sC1 + z2 * g.sC2;
+  const bf16* Rp = g.R ? reinterpret_cast<const bf16*>(g.R) + z1 * g.sR1 + z2 * g.sR2 : nullptr;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
+
+  // LDS map: [A0 | B0 | A1 | B1], 16 KiB each.
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (g.K + BK - 1) / BK;
+  uint4 ra[4], rb[4];
+  tile_load<A_RED>(A, g.lda, m0, 0, g.M, g.K, g.a_vec, ra);
+  tile_load<B_RED>(B, g.ldb, n0, 0, g.N, g.K, g.b_vec, rb);
+  tile_store<A_RED>(smem, ra);
+  tile_store<B_RED>(smem + TILE_BYTES, rb);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      tile_load<A_RED>(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, g.a_vec, ra);
+      tile_load<B_RED>(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, g.b_vec, rb);
+    }
+    const char* la = smem + cur * (2 * TILE_BYTES);
+    const char* lb = la + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 fm[2], fn[2];
+      fm[0] = frag_load<A_RED>(la, wm0, ks);
+      fm[1] = frag_load<A_RED>(la, wm0 + 32, ks);
+      fn[0] = frag_load<B_RED>(lb, wn0, ks);
+      fn[1] = frag_load<B_RED>(lb, wn0 + 32, ks);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn[j], fm[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      char* na = smem + (cur ^ 1) * (2 * TILE_BYTES);
+      tile_store<A_RED>(na, ra);
+      tile_store<B_RED>(na + TILE_BYTES, rb);
+    }
+    __syncthreads();
+  }
+
+  // Epilogue. D[i = n][j = m]: lane holds m = l&31, n = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+  const float alpha = g.alpha;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm0 + i * 32 + (l & 31);
+    if (m >= g.M) continue;
+    float bias_m = 0.f;
+    if (g.bias_mode == 2) bias_m = (float)reinterpret_cast<const bf16*>(g.bias)[m];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn0 + j * 32 + 8 * q + 4 * (l >> 5);
+        if (n >= g.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = alpha * acc[i][j][4 * q + e];
+        if (g.bias_mode == 1) {
+          const bf16* bp = reinterpret_cast<const bf16*>(g.bias) + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < g.N) v[e] += (float)bp[e];
+        } else if (g.bias_mode == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bias_m;
+        }
+        if (g.act) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], g.act);
+        }
+        bf16* cp = C + (long)m * g.ldc + n;
+        const bool full = (n + 3 < g.N) && g.c_vec;
+        if (full) {
+          if (Rp) {
+            bf16x4 rv = *reinterpret_cast<const bf16x4*>(Rp + (long)m * g.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+          }
+          if (g.accumulate) {
+            bf16x4 cv = *reinterpret_cast<const bf16x4*>(cp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)cv[e];
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+          *reinterpret_cast<bf16x4*>(cp) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e < g.N) {
+              float x = v[e];
+              if (Rp) x += (float)Rp[(long)m * g.ldr + n + e];
+              if (g.accumulate) x += (float)cp[e];
+              cp[e] = (bf16)x;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------- f32 --
+// 64x64x16 tile, 4 waves (2x2) of 32x32, v_mfma_f32_16x16x4_f32 (exact f32).
+constexpr int FBM = 64, FBN = 64, FBK = 16, FPAD = 4;
+
+template <bool RED_MAJOR>
+MK_DEV void f32_tile_load(const float* base, long ld, int row0, int k0, int R, int K,
+                          float (*lds)[FBM + FPAD]) {
+  const int t = threadIdx.x;
+  if constexpr (!RED_MAJOR) {
+    const int row = t >> 2, kq = (t & 3) * 4;
+    const int gr = row0 + row;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gk = k0 + kq + j;
+      lds[kq + j][row] = (gr < R && gk < K) ? base[(long)gr * ld + gk] : 0.f;
+    }
+  } else {
+    const int kr = t >> 4, mq = (t & 15) * 4;
+    const int gk = k0 + kr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gr = row0 + mq + j;
+      lds[kr][mq + j] = (gr < R && gk < K) ? base[(long)gk * ld + gr] : 0.f;
+    }
+  }
+}
+
+template <bool A_RED, bool B_RED>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ float As[FBK][FBM + FPAD];
+  __shared__ float Bs[FBK][FBN + FPAD];
+  int tm, tn;
+  tile_coords(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
+  const int z = blockIdx.z, z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+  const float* A = reinterpret_cast<const float*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
+  const float* B = reinterpret_cast<const float*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
+  float* C = reinterpret_cast<float*>(g.C) + z1 * g.sC1 + z2 * g.sC2;
+  const float* Rp = g.R ? reinterpret_cast<const float*>(g.R) + z1 * g.sR1 + z2 * g.sR2 : nullptr;
+  const int m0 = tm * FBM, n0 = tn * FBN;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int wm0 = (w >> 1) * 32, wn0 = (w & 1) * 32;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < g.K; k0 += FBK) {
+    f32_tile_load<A_RED>(A, g.lda, m0, k0, g.M, g.K, As);
+    f32_tile_load<B_RED>(B, g.ldb, n0, k0, g.N, g.K, Bs);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = ks * 4 + (l >> 4);
+      float fm[2], fn[2];
+      fm[0] = As[kk][wm0 + (l & 15)];
+      fm[1] = As[kk][wm0 + 16 + (l & 15)];
+      fn[0] = Bs[kk][wn0 + (l & 15)];
+      fn[1] = Bs[kk][wn0 + 16 + (l & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fn[j], fm[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[i = n][j = m]: lane holds m = l&15, n = 4*(l>>4) + reg
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm0 + i * 16 + (l & 15);
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn0 + j * 16 + 4 * (l >> 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= g.N) continue;
+        float v = g.alpha * acc[i][j][e];
+        if (g.bias_mode == 1) v += reinterpret_cast<const float*>(g.bias)[n + e];
+        else if (g.bias_mode == 2) v += reinterpret_cast<const float*>(g.bias)[m];
+        v = apply_act(v, g.act);
+        if (Rp) v += Rp[(long)m * g.ldr + n + e];
+        float* cp = C + (long)m * g.ldc + n + e;
+        if (g.accumulate) v += *cp;
+        *cp = v;
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------- transpose --
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* in, T* out, int rows, int cols,
+                                                        long ld_in, long ld_out, long s_in,
+                                                        long s_out) {
+  __shared__ T tile[64][65];
+  in += (long)blockIdx.z * s_in;
+  out += (long)blockIdx.z * s_out;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < rows && c < cols) tile[i][tx] = in[(long)r * ld_in + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) out[(long)c * ld_out + r] = tile[tx][i];
+  }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int mk_abi_version(void) { return MK_ABI_VERSION; }
+
+extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
+  if (!d || !d->A || !d->B || !d->C) return MK_ERR_BAD_ARG;
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0) return MK_ERR_BAD_ARG;
+  if (d->nb1 < 1 || d->nb2 < 1) return MK_ERR_BAD_ARG;
+  if (d->bias_mode && !d->bias) return MK_ERR_BAD_ARG;
+  if (d->dtype != MK_F32 && d->dtype != MK_BF16) return MK_ERR_UNSUPPORTED;
+  GemmArgs g;
+  g.A = d->A; g.B = d->B; g.C = d->C; g.R = d->R; g.bias = d->bias;
+  g.M = d->M; g.N = d->N; g.K = d->K;
+  g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldr = d->ldr;
+  g.nb2 = d->nb2;
+  g.sA1 = d->sA1; g.sA2 = d->sA2; g.sB1 = d->sB1; g.sB2 = d->sB2;
+  g.sC1 = d->sC1; g.sC2 = d->sC2; g.sR1 = d->sR1; g.sR2 = d->sR2;
+  g.alpha = d->alpha; g.bias_mode = d->bias_mode; g.act = d->act; g.accumulate = d->accumulate;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nbatch = d->nb1 * d->nb2;
+  if (d->dtype == MK_BF16) {
+    g.tiles_m = mk_cdiv(d->M, BM);
+    g.tiles_n = mk_cdiv(d->N, BN);
+    g.a_vec = aligned16(d->A) && (d->lda % 8 == 0) && (d->sA1 % 8 == 0) && (d->sA2 % 8 == 0);
+    g.b_vec = aligned16(d->B) && (d->ldb % 8 == 0) && (d->sB1 % 8 == 0) && (d->sB2 % 8 == 0);
+    g.c_vec = ((reinterpret_cast<uintptr_t>(d->C) & 7) == 0) && (d->ldc % 4 == 0) &&
+              (d->sC1 % 4 == 0) && (d->sC2 % 4 == 0) &&
+              (!d->R || (((reinterpret_cast<uintptr_t>(d->R) & 7) == 0) && (d->ldr % 4 == 0) &&
+                         (d->sR1 % 4 == 0) && (d->sR2 % 4 == 0)));
+    dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(256);
+    const size_t shm = 4 * TILE_BYTES;
+#define MK_LAUNCH_BF16(AR, BR)                                                              \
+  do {                                                                                      \
+    static bool attr_done = false;                                                          \
+    if (!attr_done) {                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<AR, BR>),   \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);            \
+      attr_done = true;                                                                     \
+    }                                                                                       \
+    hipLaunchKernelGGL((gemm_bf16_kernel<AR, BR>), grid, block, shm, st, g);                \
+  } while (0)
+    if (!d->a_red_major && !d->b_red_major) MK_LAUNCH_BF16(false, false);
+    else if (!d->a_red_major && d->b_red_major) MK_LAUNCH_BF16(false, true);
+    else if (d->a_red_major && !d->b_red_major) MK_LAUNCH_BF16(true, false);
+    else MK_LAUNCH_BF16(true, true);
+#undef MK_LAUNCH_BF16
+  } else {
+    g.tiles_m = mk_cdiv(d->M, FBM);
+    g.tiles_n = mk_cdiv(d->N, FBN);
+    g.a_vec = g.b_vec = g.c_vec = 0;
+    dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(256);
+    if (!d->a_red_major && !d->b_red_major)
+      hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, st, g);
+    else if (!d->a_red_major && d->b_red_major)
+      hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, st, g);
+    else if (d->a_red_major && !d->b_red_major)
+      hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, st, g);
+    else
+      hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, st, g);
+  }
+  return mk_check_launch();
+}
+
+extern "C" int mk_transpose(const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in,
+                            int64_t ld_out, int32_t batch, int64_t s_in, int64_t s_out,
+                            int32_t elem_size, void* stream) {
+  if (!in || !out || rows <= 0 || cols <= 0 || batch <= 0) return MK_ERR_BAD_ARG;
+  dim3 grid(mk_cdiv(cols, 64), mk_cdiv(rows, 64), batch), block(256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (elem_size == 2)
+    hipLaunchKernelGGL((transpose_kernel<unsigned short>), grid, block, 0, st,
+                       (const unsigned short*)in, (unsigned short*)out, rows, cols, (long)ld_in,
+                       (long)ld_out, (long)s_in, (long)s_out);
+  else if (elem_size == 4)
+    hipLaunchKernelGGL((transpose_kernel<float>), grid, block, 0, st, (const float*)in,
+                       (float*)out, rows, cols, (long)ld_in, (long)ld_out, (long)s_in,
+                       (long)s_out);
+  else
+    return MK_ERR_UNSUPPORTED;
+  return mk_check_launch();
+}

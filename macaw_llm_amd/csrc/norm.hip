@@ -1,0 +1,361 @@
+// RMSNorm / LayerNorm forward+backward and column reductions (HBM-bound).
+// One 256-thread block per row, 16-byte vector access, fp32 statistics.
+// Rows are short enough (<= 16 KiB) that the second pass hits L1/L2, so the
+// algorithmic HBM traffic is one read + one write of the activation.
+//
+// Reference numerics mirrored (modeling.py:311-319): variance in fp32, the
+// normalised value is cast to the weight dtype BEFORE the weight multiply.
+#include "common.h"
+#include "../../include/macaw_hip.h"
+
+namespace {
+
+template <typename T> MK_DEV float rnd(float v) { return to_f32<T>(from_f32<T>(v)); }
+
+// ---------------------------------------------------------------- RMSNorm --
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* x, const T* res, const T* w,
+                                                          T* h_out, T* y, float* rstd_out,
+                                                          int cols, float eps) {
+  constexpr int N = VecIO<T>::N;
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const T* xr = x + row * cols;
+  const T* rr = res ? res + row * cols : nullptr;
+  T* hr = h_out ? h_out + row * cols : nullptr;
+  T* yr = y + row * cols;
+  const int nch = cols / N;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < nch; c += 256) {
+    float v[N];
+    VecIO<T>::load(xr + c * N, v);
+    if (rr) {
+      float r[N];
+      VecIO<T>::load(rr + c * N, r);
+#pragma unroll
+      for (int i = 0; i < N; ++i) v[i] = rnd<T>(v[i] + r[i]);
+      VecIO<T>::store(hr + c * N, v);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) ss += v[i] * v[i];
+  }
+  for (int c = nch * N + threadIdx.x; c < cols; c += 256) {  // scalar tail
+    float v = to_f32<T>(xr[c]);
+    if (rr) { v = rnd<T>(v + to_f32<T>(rr[c])); hr[c] = from_f32<T>(v); }
+    ss += v * v;
+  }
+  ss = block_sum<256>(ss, red);
+  const float rstd = rsqrtf(ss / (float)cols + eps);
+  if (threadIdx.x == 0) rstd_out[row] = rstd;
+  const T* src = rr ? hr : xr;
+  for (int c = threadIdx.x; c < nch; c += 256) {
+    float v[N], g[N];
+    VecIO<T>::load(src + c * N, v);
+    VecIO<T>::load(w + c * N, g);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = g[i] * rnd<T>(v[i] * rstd);
+    VecIO<T>::store(yr + c * N, v);
+  }
+  for (int c = nch * N + threadIdx.x; c < cols; c += 256)
+    yr[c] = from_f32<T>(to_f32<T>(w[c]) * rnd<T>(to_f32<T>(src[c]) * rstd));
+}
+
+// dx = dres + rstd * (dn - n * mean(dn * n)), dn = dy*w, n = h*rstd.
+// Block b owns rows b, b+nblk, ... and keeps its dw column sums in registers.
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* h, const T* w,
+                                                          const float* rstd, const T* dres, T* dx,
+                                                          float* dw_partial, int rows, int cols) {
+  constexpr int N = VecIO<T>::N;
+  __shared__ float red[16];
+  const int nch = cols / N;  // cols % N == 0 enforced by the host
+  float dwacc[CH][N];
+  float wv[CH][N];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = threadIdx.x + 256 * k;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { dwacc[k][i] = 0.f; wv[k][i] = 0.f; }
+    if (c < nch) VecIO<T>::load(w + c * N, wv[k]);
+  }
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const float rs = rstd[row];
+    float dyv[CH][N], nv[CH][N];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = threadIdx.x + 256 * k;
+      if (c < nch) {
+        VecIO<T>::load(dy + row * cols + c * N, dyv[k]);
+        VecIO<T>::load(h + row * cols + c * N, nv[k]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          nv[k][i] *= rs;
+          dwacc[k][i] += dyv[k][i] * nv[k][i];
+          dyv[k][i] *= wv[k][i];
+          dot += dyv[k][i] * nv[k][i];
+        }
+      }
+    }
+    dot = block_sum<256>(dot, red) / (float)cols;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = threadIdx.x + 256 * k;
+      if (c < nch) {
+        float o[N];
+        if (dres) VecIO<T>::load(dres + row * cols + c * N, o);
+        else {
+#pragma unroll
+          for (int i = 0; i < N; ++i) o[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[i] += rs * (dyv[k][i] - nv[k][i] * dot);
+        VecIO<T>::store(dx + row * cols + c * N, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = threadIdx.x + 256 * k;
+    if (c < nch) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) dw_partial[(long)blockIdx.x * cols + c * N + i] = dwacc[k][i];
+    }
+  }
+}
+
+// -------------------------------------------------------------- LayerNorm --
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const T* w, const T* b,
+                                                            T* y, float* mean_out, float* rstd_out,
+                                                            int cols, float eps) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const T* xr = x + row * cols;
+  T* yr = y + row * cols;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) s += to_f32<T>(xr[c]);
+  const float mean = block_sum<256>(s, red) / (float)cols;
+  float v = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const float d = to_f32<T>(xr[c]) - mean;
+    v += d * d;
+  }
+  const float var = block_sum<256>(v, red) / (float)cols;
+  const float rstd = rsqrtf(var + eps);
+  if (threadIdx.x == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  for (int c = threadIdx.x; c < cols; c += 256)
+    yr[c] = from_f32<T>((to_f32<T>(xr[c]) - mean) * rstd * to_f32<T>(w[c]) + to_f32<T>(b[c]));
+}
+
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const T* w,
+                                                            const float* mean, const float* rstd,
+                                                            const T* dres, T* dx, float* dw_partial,
+                                                            float* db_partial, int rows, int cols) {
+  __shared__ float red[16];
+  float dwacc[CH], dbacc[CH], wv[CH];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = threadIdx.x + 256 * k;
+    dwacc[k] = 0.f; dbacc[k] = 0.f;
+    wv[k] = (c < cols) ? to_f32<T>(w[c]) : 0.f;
+  }
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const float mu = mean[row], rs = rstd[row];
+    float g[CH], xh[CH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = threadIdx.x + 256 * k;
+      g[k] = 0.f; xh[k] = 0.f;
+      if (c < cols) {
+        const float d = to_f32<T>(dy[row * cols + c]);
+        xh[k] = (to_f32<T>(x[row * cols + c]) - mu) * rs;
+        dwacc[k] += d * xh[k];
+        dbacc[k] += d;
+        g[k] = d * wv[k];
+        s1 += g[k];
+        s2 += g[k] * xh[k];
+      }
+    }
+    s1 = block_sum<256>(s1, red) / (float)cols;
+    s2 = block_sum<256>(s2, red) / (float)cols;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = threadIdx.x + 256 * k;
+      if (c < cols) {
+        float o = rs * (g[k] - s1 - xh[k] * s2);
+        if (dres) o += to_f32<T>(dres[row * cols + c]);
+        dx[row * cols + c] = from_f32<T>(o);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = threadIdx.x + 256 * k;
+    if (c < cols) {
+      dw_partial[(long)blockIdx.x * cols + c] = dwacc[k];
+      db_partial[(long)blockIdx.x * cols + c] = dbacc[k];
+    }
+  }
+}
+
+// out[c] (+)= sum_b partial[b][c]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* partial, T* out,
+                                                              int nblk, int cols, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(long)b * cols + c];
+  if (accumulate) s += to_f32<T>(out[c]);
+  out[c] = from_f32<T>(s);
+}
+
+// partial[b][c] = sum over the block's row slab of x[r][c]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const T* x, long ld, float* partial,
+                                                          int rows, int cols) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (long r = blockIdx.y; r < rows; r += gridDim.y) s += to_f32<T>(x[r * ld + c]);
+  partial[(long)blockIdx.y * cols + c] = s;
+}
+
+template <typename T>
+int rmsnorm_bwd_launch(const void* dy, const void* h, const void* w, const float* rstd,
+                       const void* dres, void* dx, float* dwp, int nblk, int rows, int cols,
+                       hipStream_t st) {
+  constexpr int N = VecIO<T>::N;
+  if (cols % N) return MK_ERR_UNSUPPORTED;
+  const int ch = mk_cdiv(cols / N, 256);
+  dim3 grid(nblk), block(256);
+#define MK_RB(CHV)                                                                             \
+  hipLaunchKernelGGL((rmsnorm_bwd_kernel<T, CHV>), grid, block, 0, st, (const T*)dy, (const T*)h, \
+                     (const T*)w, rstd, (const T*)dres, (T*)dx, dwp, rows, cols)
+  if (ch <= 1) MK_RB(1);
+  else if (ch <= 2) MK_RB(2);
+  else if (ch <= 4) MK_RB(4);
+  else if (ch <= 8) MK_RB(8);
+  else return MK_ERR_UNSUPPORTED;
+#undef MK_RB
+  return mk_check_launch();
+}
+
+template <typename T>
+int layernorm_bwd_launch(const void* dy, const void* x, const void* w, const float* mean,
+                         const float* rstd, const void* dres, void* dx, float* dwp, float* dbp,
+                         int nblk, int rows, int cols, hipStream_t st) {
+  const int ch = mk_cdiv(cols, 256);
+  dim3 grid(nblk), block(256);
+#define MK_LB(CHV)                                                                          \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T, CHV>), grid, block, 0, st, (const T*)dy,      \
+                     (const T*)x, (const T*)w, mean, rstd, (const T*)dres, (T*)dx, dwp, dbp, \
+                     rows, cols)
+  if (ch <= 1) MK_LB(1);
+  else if (ch <= 2) MK_LB(2);
+  else if (ch <= 4) MK_LB(4);
+  else if (ch <= 8) MK_LB(8);
+  else if (ch <= 16) MK_LB(16);
+  else if (ch <= 32) MK_LB(32);
+  else return MK_ERR_UNSUPPORTED;
+#undef MK_LB
+  return mk_check_launch();
+}
+
+}  // namespace
+
+#define MK_ST reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int mk_rmsnorm_fwd(const void* x, const void* res, const void* w, void* h_out, void* y,
+                              float* rstd, int32_t rows, int32_t cols, float eps, int32_t dtype,
+                              void* stream) {
+  if (!x || !w || !y || !rstd || rows <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
+  if (res && !h_out) return MK_ERR_BAD_ARG;
+  dim3 grid(rows), block(256);
+  if (dtype == MK_BF16) {
+    if (cols % 8) return MK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((rmsnorm_fwd_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x,
+                       (const bf16*)res, (const bf16*)w, (bf16*)h_out, (bf16*)y, rstd, cols, eps);
+  } else if (dtype == MK_F32) {
+    if (cols % 4) return MK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((rmsnorm_fwd_kernel<float>), grid, block, 0, MK_ST, (const float*)x,
+                       (const float*)res, (const float*)w, (float*)h_out, (float*)y, rstd, cols,
+                       eps);
+  } else return MK_ERR_UNSUPPORTED;
+  return mk_check_launch();
+}
+
+extern "C" int mk_rmsnorm_bwd(const void* dy, const void* h, const void* w, const float* rstd,
+                              const void* dres_in, void* dx, float* dw_partial, int32_t nblk,
+                              int32_t rows, int32_t cols, int32_t dtype, void* stream) {
+  if (!dy || !h || !w || !rstd || !dx || !dw_partial || nblk <= 0 || rows <= 0) return MK_ERR_BAD_ARG;
+  if (dtype == MK_BF16)
+    return rmsnorm_bwd_launch<bf16>(dy, h, w, rstd, dres_in, dx, dw_partial, nblk, rows, cols, MK_ST);
+  if (dtype == MK_F32)
+    return rmsnorm_bwd_launch<float>(dy, h, w, rstd, dres_in, dx, dw_partial, nblk, rows, cols, MK_ST);
+  return MK_ERR_UNSUPPORTED;
+}
+
+extern "C" int mk_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean,
+                                float* rstd, int32_t rows, int32_t cols, float eps, int32_t dtype,
+                                void* stream) {
+  if (!x || !w || !b || !y || !mean || !rstd || rows <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
+  dim3 grid(rows), block(256);
+  if (dtype == MK_BF16)
+    hipLaunchKernelGGL((layernorm_fwd_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x,
+                       (const bf16*)w, (const bf16*)b, (bf16*)y, mean, rstd, cols, eps);
+  else if (dtype == MK_F32)
+    hipLaunchKernelGGL((layernorm_fwd_kernel<float>), grid, block, 0, MK_ST, (const float*)x,
+                       (const float*)w, (const float*)b, (float*)y, mean, rstd, cols, eps);
+  else return MK_ERR_UNSUPPORTED;
+  return mk_check_launch();
+}
+
+extern "C" int mk_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean,
+                                const float* rstd, const void* dres_in, void* dx,
+                                float* dw_partial, float* db_partial, int32_t nblk, int32_t rows,
+                                int32_t cols, int32_t dtype, void* stream) {
+  if (!dy || !x || !w || !mean || !rstd || !dx || !dw_partial || !db_partial || nblk <= 0)
+    return MK_ERR_BAD_ARG;
+  if (dtype == MK_BF16)
+    return layernorm_bwd_launch<bf16>(dy, x, w, mean, rstd, dres_in, dx, dw_partial, db_partial,
+                                      nblk, rows, cols, MK_ST);
+  if (dtype == MK_F32)
+    return layernorm_bwd_launch<float>(dy, x, w, mean, rstd, dres_in, dx, dw_partial, db_partial,
+                                       nblk, rows, cols, MK_ST);
+  return MK_ERR_UNSUPPORTED;
+}
+
+extern "C" int mk_colsum_partials(const float* partial, void* out, int32_t nblk, int32_t cols,
+                                  int32_t accumulate, int32_t dtype, void* stream) {
+  if (!partial || !out || nblk <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
+  dim3 grid(mk_cdiv(cols, 256)), block(256);
+  if (dtype == MK_BF16)
+    hipLaunchKernelGGL((colsum_partials_kernel<bf16>), grid, block, 0, MK_ST, partial, (bf16*)out,
+                       nblk, cols, accumulate);
+  else if (dtype == MK_F32)
+    hipLaunchKernelGGL((colsum_partials_kernel<float>), grid, block, 0, MK_ST, partial,
+                       (float*)out, nblk, cols, accumulate);
+  else return MK_ERR_UNSUPPORTED;
+  return mk_check_launch();
+}
+
+extern "C" int mk_colsum(const void* x, int64_t ld, void* out, float* ws, int32_t nblk,
+                         int32_t rows, int32_t cols, int32_t accumulate, int32_t dtype,
+                         void* stream) {
+  if (!x || !out || !ws || nblk <= 0 || rows <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
+  dim3 grid(mk_cdiv(cols, 256), nblk), block(256);
+  if (dtype == MK_BF16)
+    hipLaunchKernelGGL((colsum_rows_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x, (long)ld,
+                       ws, rows, cols);
+  else if (dtype == MK_F32)
+    hipLaunchKernelGGL((colsum_rows_kernel<float>), grid, block, 0, MK_ST, (const float*)x,
+                       (long)ld, ws, rows, cols);
+  else return MK_ERR_UNSUPPORTED;
+  int rc = mk_check_launch();
+  if (rc) return rc;
+  return mk_colsum_partials(ws, out, nblk, cols, accumulate, dtype, stream);
+}

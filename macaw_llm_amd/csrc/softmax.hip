@@ -1,0 +1,357 @@
+// Row softmax with the reference's masking semantics, its backward, attention
+// dropout, shifted cross-entropy, and the fused AdamW update.  All HBM-bound.
+//
+// Masking (modeling.py:205-214, 44-73): masked logits take finfo(dtype).min —
+// exactly what `scores + mask` followed by `max(., finfo.min)` produces — and
+// the softmax itself runs in fp32.  A fully masked row therefore degenerates to
+// a uniform distribution, not NaN.
+#include "common.h"
+#include "../../include/macaw_hip.h"
+
+namespace {
+
+template <typename T> MK_DEV float finfo_min();
+template <> MK_DEV float finfo_min<float>() { return -3.4028234663852886e38f; }
+template <> MK_DEV float finfo_min<bf16>() { return -3.3895313892515355e38f; }
+
+MK_DEV uint32_t keep_thr(float p) {
+  const double k = (1.0 - (double)p) * 4294967296.0;
+  return k >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)k;
+}
+
+// One wave per row (Lk <= 64*MAXE), values held in registers.
+template <typename T, int MAXE>
+__global__ __launch_bounds__(256) void softmax_fwd_wave_kernel(
+    const T* scores, T* probs, T* probs_drop, const int32_t* kmask, long nrows, int heads, int Lq,
+    int Lk, long ld, int causal, float p, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int q = (int)(row % Lq);
+  const long z = row / Lq;
+  const long b = z / heads;
+  const T* sr = scores + row * ld;
+  const int klim = causal ? q + (Lk - Lq) : Lk - 1;  // keys > klim are masked
+  const float lowest = finfo_min<T>();
+  float v[MAXE];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const int k = lane + 64 * e;
+    v[e] = -INFINITY;
+    if (k < Lk) {
+      float s = to_f32<T>(sr[k]);
+      if (k > klim || (kmask && kmask[b * Lk + k] == 0)) s = lowest;
+      v[e] = s;
+      mx = fmaxf(mx, s);
+    }
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const int k = lane + 64 * e;
+    if (k < Lk) { v[e] = __expf(v[e] - mx); sum += v[e]; }
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  const uint32_t thr = keep_thr(p);
+  const float dscale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const int k = lane + 64 * e;
+    if (k < Lk) {
+      const T pv = from_f32<T>(v[e] * inv);
+      probs[row * ld + k] = pv;
+      if (probs_drop) {
+        const bool keep = mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr);
+        probs_drop[row * ld + k] = keep ? from_f32<T>(to_f32<T>(pv) * dscale) : from_f32<T>(0.f);
+      }
+    }
+  }
+}
+
+// One 256-thread block per row (long rows, e.g. the 32,009-key alignment attention).
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_block_kernel(
+    const T* scores, T* probs, T* probs_drop, const int32_t* kmask, int heads, int Lq, int Lk,
+    long ld, int causal, float p, uint64_t seed) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const int q = (int)(row % Lq);
+  const long z = row / Lq;
+  const long b = z / heads;
+  const T* sr = scores + row * ld;
+  const int klim = causal ? q + (Lk - Lq) : Lk - 1;
+  const float lowest = finfo_min<T>();
+  float mx = -INFINITY;
+  for (int k = threadIdx.x; k < Lk; k += 256) {
+    float s = to_f32<T>(sr[k]);
+    if (k > klim || (kmask && kmask[b * Lk + k] == 0)) s = lowest;
+    mx = fmaxf(mx, s);
+  }
+  mx = block_max<256>(mx, red);
+  float sum = 0.f;
+  for (int k = threadIdx.x; k < Lk; k += 256) {
+    float s = to_f32<T>(sr[k]);
+    if (k > klim || (kmask && kmask[b * Lk + k] == 0)) s = lowest;
+    sum += __expf(s - mx);
+  }
+  sum = block_sum<256>(sum, red);
+  const float inv = 1.f / sum;
+  const uint32_t thr = keep_thr(p);
+  const float dscale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (int k = threadIdx.x; k < Lk; k += 256) {
+    float s = to_f32<T>(sr[k]);
+    if (k > klim || (kmask && kmask[b * Lk + k] == 0)) s = lowest;
+    const T pv = from_f32<T>(__expf(s - mx) * inv);
+    probs[row * ld + k] = pv;
+    if (probs_drop) {
+      const bool keep = mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr);
+      probs_drop[row * ld + k] = keep ? from_f32<T>(to_f32<T>(pv) * dscale) : from_f32<T>(0.f);
+    }
+  }
+}
+
+// dS = P .* (g - sum(g .* P)) * scale,  g = dP_drop .* keep/(1-p); in place on dprobs.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* probs, T* dprobs, int Lk,
+                                                          long ld, float scale, float p,
+                                                          uint64_t seed, long nrows,
+                                                          int wave_per_row) {
+  __shared__ float red[16];
+  const uint32_t thr = keep_thr(p);
+  const float dscale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  if (wave_per_row) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    float dot = 0.f;
+    for (int k = lane; k < Lk; k += 64) {
+      float g = to_f32<T>(dprobs[row * ld + k]);
+      if (p > 0.f) g = mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr) ? g * dscale : 0.f;
+      dot += g * to_f32<T>(probs[row * ld + k]);
+    }
+    dot = wave_sum(dot);
+    for (int k = lane; k < Lk; k += 64) {
+      float g = to_f32<T>(dprobs[row * ld + k]);
+      if (p > 0.f) g = mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr) ? g * dscale : 0.f;
+      dprobs[row * ld + k] = from_f32<T>(to_f32<T>(probs[row * ld + k]) * (g - dot) * scale);
+    }
+  } else {
+    const long row = blockIdx.x;
+    float dot = 0.f;
+    for (int k = threadIdx.x; k < Lk; k += 256) {
+      float g = to_f32<T>(dprobs[row * ld + k]);
+      if (p > 0.f) g = mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr) ? g * dscale : 0.f;
+      dot += g * to_f32<T>(probs[row * ld + k]);
+    }
+    dot = block_sum<256>(dot, red);
+    for (int k = threadIdx.x; k < Lk; k += 256) {
+      float g = to_f32<T>(dprobs[row * ld + k]);
+      if (p > 0.f) g = mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr) ? g * dscale : 0.f;
+      dprobs[row * ld + k] = from_f32<T>(to_f32<T>(probs[row * ld + k]) * (g - dot) * scale);
+    }
+  }
+}
+
+// ---------------------------------------------------------- cross entropy --
+// row_stat[r] = {lse} ; row_loss[r] = lse - logit[label] (0 when ignored)
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const T* logits, const int64_t* labels,
+                                                     float* row_loss, float* row_lse, int V,
+                                                     long ld) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const T* lr = logits + row * ld;
+  const long lab = labels[row];
+  if (lab < 0 || lab >= V) {  // ignore_index (-100) or out of range: no contribution
+    if (threadIdx.x == 0) { row_loss[row] = 0.f; row_lse[row] = 0.f; }
+    return;
+  }
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, to_f32<T>(lr[c]));
+  mx = block_max<256>(mx, red);
+  float sum = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) sum += __expf(to_f32<T>(lr[c]) - mx);
+  sum = block_sum<256>(sum, red);
+  if (threadIdx.x == 0) {
+    const float lse = mx + __logf(sum);
+    row_lse[row] = lse;
+    row_loss[row] = lse - to_f32<T>(lr[lab]);
+  }
+}
+// Deterministic single-block reduction: out = {sum loss, n_valid}
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* row_loss,
+                                                        const int64_t* labels, float* out,
+                                                        int rows, int V) {
+  __shared__ float red[16];
+  float s = 0.f, n = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const long lab = labels[r];
+    if (lab >= 0 && lab < V) { s += row_loss[r]; n += 1.f; }
+  }
+  s = block_sum<256>(s, red);
+  n = block_sum<256>(n, red);
+  if (threadIdx.x == 0) { out[0] = s; out[1] = n; }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const T* logits, T* dlogits,
+                                                     const int64_t* labels, const float* row_lse,
+                                                     const float* sum_cnt, float grad_scale, int V,
+                                                     long ld) {
+  const long row = blockIdx.x;
+  const T* lr = logits + row * ld;
+  T* dr = dlogits + row * ld;
+  const long lab = labels[row];
+  const bool valid = lab >= 0 && lab < V;
+  const float n = sum_cnt[1];
+  const float gs = (valid && n > 0.f) ? grad_scale / n : 0.f;
+  const float lse = row_lse[row];
+  for (int c = threadIdx.x; c < (int)ld; c += 256) {
+    float g = 0.f;
+    if (valid && c < V) g = (__expf(to_f32<T>(lr[c]) - lse) - (c == lab ? 1.f : 0.f)) * gs;
+    dr[c] = from_f32<T>(g);
+  }
+}
+
+// ------------------------------------------------------------------ AdamW --
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_kernel(T* param, float* master, float* m, float* v,
+                                                    const T* grad, long n, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1,
+                                                    float bc2, float gscale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float g = to_f32<T>(grad[i]) * gscale;
+    float w = master[i];
+    const float mi = b1 * m[i] + (1.f - b1) * g;
+    const float vi = b2 * v[i] + (1.f - b2) * g * g;
+    m[i] = mi; v[i] = vi;
+    w -= lr * wd * w;  // decoupled weight decay
+    w -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    master[i] = w;
+    param[i] = from_f32<T>(w);
+  }
+}
+
+}  // namespace
+
+#define MK_ST reinterpret_cast<hipStream_t>(stream)
+
+namespace {
+template <typename T>
+int softmax_fwd_t(const void* scores, void* probs, void* probs_drop, const int32_t* kmask,
+                  int nz, int heads, int Lq, int Lk, long ld, int causal, float p, uint64_t seed,
+                  hipStream_t st) {
+  const long nrows = (long)nz * Lq;
+  if (Lk <= 64 * 16) {
+    dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
+#define MK_SW(E)                                                                               \
+  hipLaunchKernelGGL((softmax_fwd_wave_kernel<T, E>), grid, block, 0, st, (const T*)scores,     \
+                     (T*)probs, (T*)probs_drop, kmask, nrows, heads, Lq, Lk, ld, causal, p, seed)
+    if (Lk <= 64) MK_SW(1);
+    else if (Lk <= 128) MK_SW(2);
+    else if (Lk <= 256) MK_SW(4);
+    else if (Lk <= 512) MK_SW(8);
+    else MK_SW(16);
+#undef MK_SW
+  } else {
+    hipLaunchKernelGGL((softmax_fwd_block_kernel<T>), dim3((unsigned)nrows), dim3(256), 0, st,
+                       (const T*)scores, (T*)probs, (T*)probs_drop, kmask, heads, Lq, Lk, ld,
+                       causal, p, seed);
+  }
+  return mk_check_launch();
+}
+}  // namespace
+
+extern "C" int mk_softmax_fwd(const void* scores, void* probs, void* probs_drop,
+                              const int32_t* kmask, int32_t nz, int32_t heads, int32_t Lq,
+                              int32_t Lk, int64_t ld, int32_t causal, float dropout_p,
+                              uint64_t seed, int32_t dtype, void* stream) {
+  if (!scores || !probs || nz <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0 || ld < Lk)
+    return MK_ERR_BAD_ARG;
+  if (dropout_p < 0.f || dropout_p >= 1.f) return MK_ERR_BAD_ARG;
+  if (dropout_p == 0.f) probs_drop = nullptr;
+  if (dtype == MK_BF16)
+    return softmax_fwd_t<bf16>(scores, probs, probs_drop, kmask, nz, heads, Lq, Lk, ld, causal,
+                               dropout_p, seed, MK_ST);
+  if (dtype == MK_F32)
+    return softmax_fwd_t<float>(scores, probs, probs_drop, kmask, nz, heads, Lq, Lk, ld, causal,
+                                dropout_p, seed, MK_ST);
+  return MK_ERR_UNSUPPORTED;
+}
+
+extern "C" int mk_softmax_bwd(const void* probs, void* dprobs, int32_t nz, int32_t Lq, int32_t Lk,
+                              int64_t ld, float scale, float dropout_p, uint64_t seed,
+                              int32_t dtype, void* stream) {
+  if (!probs || !dprobs || nz <= 0 || Lq <= 0 || Lk <= 0 || ld < Lk) return MK_ERR_BAD_ARG;
+  const long nrows = (long)nz * Lq;
+  const int wpr = Lk <= 1024;
+  dim3 grid((unsigned)(wpr ? (nrows + 3) / 4 : nrows)), block(256);
+  if (dtype == MK_BF16)
+    hipLaunchKernelGGL((softmax_bwd_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)probs,
+                       (bf16*)dprobs, Lk, (long)ld, scale, dropout_p, seed, nrows, wpr);
+  else if (dtype == MK_F32)
+    hipLaunchKernelGGL((softmax_bwd_kernel<float>), grid, block, 0, MK_ST, (const float*)probs,
+                       (float*)dprobs, Lk, (long)ld, scale, dropout_p, seed, nrows, wpr);
+  else return MK_ERR_UNSUPPORTED;
+  return mk_check_launch();
+}
+
+extern "C" int mk_cross_entropy(const void* logits, const int64_t* labels, float* row_loss,
+                                float* row_lse, float* loss_sum_cnt, int32_t rows, int32_t V,
+                                int64_t ld, int32_t dtype, void* stream) {
+  if (!logits || !labels || !row_loss || !row_lse || !loss_sum_cnt || rows <= 0 || V <= 0 ||
+      ld < V)
+    return MK_ERR_BAD_ARG;
+  if (dtype == MK_BF16)
+    hipLaunchKernelGGL((ce_fwd_kernel<bf16>), dim3(rows), dim3(256), 0, MK_ST, (const bf16*)logits,
+                       labels, row_loss, row_lse, V, (long)ld);
+  else if (dtype == MK_F32)
+    hipLaunchKernelGGL((ce_fwd_kernel<float>), dim3(rows), dim3(256), 0, MK_ST,
+                       (const float*)logits, labels, row_loss, row_lse, V, (long)ld);
+  else return MK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, MK_ST, row_loss, labels,
+                     loss_sum_cnt, rows, V);
+  return mk_check_launch();
+}
+
+extern "C" int mk_cross_entropy_bwd(const void* logits, void* dlogits, const int64_t* labels,
+                                    const float* row_lse, const float* loss_sum_cnt,
+                                    float grad_scale, int32_t rows, int32_t V, int64_t ld,
+                                    int32_t dtype, void* stream) {
+  if (!logits || !dlogits || !labels || !row_lse || !loss_sum_cnt || rows <= 0 || V <= 0 ||
+      ld < V)
+    return MK_ERR_BAD_ARG;
+  if (dtype == MK_BF16)
+    hipLaunchKernelGGL((ce_bwd_kernel<bf16>), dim3(rows), dim3(256), 0, MK_ST, (const bf16*)logits,
+                       (bf16*)dlogits, labels, row_lse, loss_sum_cnt, grad_scale, V, (long)ld);
+  else if (dtype == MK_F32)
+    hipLaunchKernelGGL((ce_bwd_kernel<float>), dim3(rows), dim3(256), 0, MK_ST,
+                       (const float*)logits, (float*)dlogits, labels, row_lse, loss_sum_cnt,
+                       grad_scale, V, (long)ld);
+  else return MK_ERR_UNSUPPORTED;
+  return mk_check_launch();
+}
+
+extern "C" int mk_adamw(void* param, float* master, float* m, float* v, const void* grad,
+                        int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int32_t step, float grad_scale, int32_t dtype,
+                        void* stream) {
+  if (!param || !master || !m || !v || !grad || n <= 0 || step < 1) return MK_ERR_BAD_ARG;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  long nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  dim3 grid((unsigned)nb), block(256);
+  if (dtype == MK_BF16)
+    hipLaunchKernelGGL((adamw_kernel<bf16>), grid, block, 0, MK_ST, (bf16*)param, master, m, v,
+                       (const bf16*)grad, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                       grad_scale);
+  else if (dtype == MK_F32)
+    hipLaunchKernelGGL((adamw_kernel<float>), grid, block, 0, MK_ST, (float*)param, master, m, v,
+                       (const float*)grad, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                       grad_scale);
+  else return MK_ERR_UNSUPPORTED;
+  return mk_check_launch();
+}

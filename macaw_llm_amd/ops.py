@@ -1,0 +1,387 @@
+"""Tensor-level wrappers over the C ABI (ctypes).  PyTorch is used only for
+device memory and the current HIP stream; every arithmetic op below runs in a
+hand-written gfx950 kernel from csrc/.
+
+All wrappers require CUDA(HIP) tensors and raise MacawHipError otherwise —
+there is no eager / CPU fallback on the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as _L
+from .lib import GemmDesc, MacawHipError, MK_BF16, MK_F16, MK_F32
+
+_DT = {torch.float32: MK_F32, torch.bfloat16: MK_BF16, torch.float16: MK_F16}
+_null = None
+
+
+def dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise MacawHipError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MacawHipError("macaw_llm_amd ops need device tensors (HIP); no CPU fallback exists")
+    return t.data_ptr()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rowmajor(t: torch.Tensor) -> int:
+    """leading dimension of a 2-D row-major (possibly pitched) tensor"""
+    if t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1):
+        raise MacawHipError(f"expected row-major 2-D tensor, got {tuple(t.shape)} {t.stride()}")
+    return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+
+
+# ------------------------------------------------------------------- GEMM --
+def gemm_raw(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_red=False, b_red=False, R=None, ldr=0,
+             bias=None, bias_mode=0, act=0, accumulate=False, alpha=1.0, nb1=1, nb2=1,
+             sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), a_off=0, b_off=0, c_off=0, r_off=0):
+    """Direct struct fill. *_off are element offsets added to the base pointers."""
+    lib = _L.load()
+    es = A.element_size()
+    d = GemmDesc()
+    d.A = _p(A) + a_off * es
+    d.B = _p(B) + b_off * es
+    d.C = _p(Cc) + c_off * es
+    d.R = (_p(R) + r_off * es) if R is not None else None
+    d.bias = _p(bias) if bias is not None else None
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    d.a_red_major, d.b_red_major = int(a_red), int(b_red)
+    d.nb1, d.nb2 = nb1, nb2
+    d.sA1, d.sA2 = sA
+    d.sB1, d.sB2 = sB
+    d.sC1, d.sC2 = sC
+    d.sR1, d.sR2 = sR
+    d.alpha = alpha
+    d.bias_mode = bias_mode if bias is not None else 0
+    d.act = act
+    d.accumulate = int(accumulate)
+    d.dtype = dt(A)
+    if B.dtype != A.dtype or Cc.dtype != A.dtype:
+        raise MacawHipError("gemm: mixed dtypes")
+    _L.check(lib.mk_gemm(C.byref(d), _st()), "mk_gemm")
+    return Cc
+
+
+def linear_fwd(x, W, bias=None, act=0, residual=None, out=None, alpha=1.0):
+    """y[M,N] = act(alpha * x[M,K] @ W[N,K]^T + bias) + residual"""
+    M, K = x.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    gemm_raw(x, W, out, M, N, K, _rowmajor(x), _rowmajor(W), _rowmajor(out), bias=bias,
+             bias_mode=1, act=act, R=residual, ldr=_rowmajor(residual) if residual is not None else 0,
+             alpha=alpha)
+    return out
+
+
+def linear_dx(dy, W, out=None, accumulate=False, residual=None):
+    """dx[M,K] = dy[M,N] @ W[N,K]  (W consumed red-major: no transpose pass)"""
+    M, N = dy.shape
+    K = W.shape[1]
+    if out is None:
+        out = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+    gemm_raw(dy, W, out, M, K, N, _rowmajor(dy), _rowmajor(W), _rowmajor(out), b_red=True,
+             accumulate=accumulate, R=residual,
+             ldr=_rowmajor(residual) if residual is not None else 0)
+    return out
+
+
+def linear_dw(dy, x, out=None, accumulate=False):
+    """dW[N,K] = dy[M,N]^T @ x[M,K]  (both operands red-major)"""
+    M, N = dy.shape
+    K = x.shape[1]
+    if out is None:
+        out = torch.empty((N, K), dtype=dy.dtype, device=dy.device)
+    gemm_raw(dy, x, out, N, K, M, _rowmajor(dy), _rowmajor(x), _rowmajor(out), a_red=True,
+             b_red=True, accumulate=accumulate)
+    return out
+
+
+def transpose(x, out=None):
+    """out[c, r] = x[r, c] for a 2-D row-major tensor (batched form: 3-D contiguous)."""
+    lib = _L.load()
+    if x.dim() == 2:
+        rows, cols = x.shape
+        if out is None:
+            out = torch.empty((cols, rows), dtype=x.dtype, device=x.device)
+        _L.check(lib.mk_transpose(_p(x), _p(out), rows, cols, _rowmajor(x), _rowmajor(out), 1, 0, 0,
+                                  x.element_size(), _st()), "mk_transpose")
+        return out
+    b, rows, cols = x.shape
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty((b, cols, rows), dtype=x.dtype, device=x.device)
+    _L.check(lib.mk_transpose(_p(x), _p(out), rows, cols, cols, rows, b, rows * cols, rows * cols,
+                              x.element_size(), _st()), "mk_transpose")
+    return out
+
+
+# ------------------------------------------------------------------ norms --
+NORM_BLOCKS = 512  # row-slab blocks for the weight-gradient partial sums
+
+
+def rmsnorm_fwd(x, w, eps, res=None):
+    """returns (h, y, rstd); h = x (+ res) — h is x itself when res is None"""
+    lib = _L.load()
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    h = torch.empty_like(x) if res is not None else x
+    _L.check(lib.mk_rmsnorm_fwd(_p(x), _p(res), _p(w), _p(h) if res is not None else None, _p(y),
+                                _p(rstd), rows, cols, eps, dt(x), _st()), "mk_rmsnorm_fwd")
+    return h, y, rstd
+
+
+def rmsnorm_bwd(dy, h, w, rstd, dres=None, dw_out=None, dw_accumulate=False):
+    """returns (dx, dw); dx = dres + d/dh, dw in w.dtype"""
+    lib = _L.load()
+    rows, cols = h.shape
+    nblk = min(NORM_BLOCKS, rows)
+    dx = torch.empty_like(h)
+    part = torch.empty((nblk, cols), dtype=torch.float32, device=h.device)
+    _L.check(lib.mk_rmsnorm_bwd(_p(dy), _p(h), _p(w), _p(rstd), _p(dres), _p(dx), _p(part), nblk,
+                                rows, cols, dt(h), _st()), "mk_rmsnorm_bwd")
+    if dw_out is None:
+        dw_out = torch.empty_like(w)
+        dw_accumulate = False
+    _L.check(lib.mk_colsum_partials(_p(part), _p(dw_out), nblk, cols, int(dw_accumulate),
+                                    dt(w), _st()), "mk_colsum_partials")
+    return dx, dw_out
+
+
+def layernorm_fwd(x, w, b, eps):
+    lib = _L.load()
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _L.check(lib.mk_layernorm_fwd(_p(x), _p(w), _p(b), _p(y), _p(mean), _p(rstd), rows, cols, eps,
+                                  dt(x), _st()), "mk_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dres=None):
+    """returns (dx, dw, db)"""
+    lib = _L.load()
+    rows, cols = x.shape
+    nblk = min(NORM_BLOCKS, rows)
+    dx = torch.empty_like(x)
+    pw = torch.empty((nblk, cols), dtype=torch.float32, device=x.device)
+    pb = torch.empty((nblk, cols), dtype=torch.float32, device=x.device)
+    _L.check(lib.mk_layernorm_bwd(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dres), _p(dx),
+                                  _p(pw), _p(pb), nblk, rows, cols, dt(x), _st()),
+             "mk_layernorm_bwd")
+    dw = torch.empty_like(w)
+    db = torch.empty_like(w)
+    _L.check(lib.mk_colsum_partials(_p(pw), _p(dw), nblk, cols, 0, dt(w), _st()), "colsum")
+    _L.check(lib.mk_colsum_partials(_p(pb), _p(db), nblk, cols, 0, dt(w), _st()), "colsum")
+    return dx, dw, db
+
+
+def colsum(x, out=None, accumulate=False):
+    """out[c] (+)= sum_r x[r, c]  (bias gradient)"""
+    lib = _L.load()
+    rows, cols = x.shape
+    nblk = max(1, min(256, rows // 16))
+    ws = torch.empty((nblk, cols), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(cols, dtype=x.dtype, device=x.device)
+        accumulate = False
+    _L.check(lib.mk_colsum(_p(x), _rowmajor(x), _p(out), _p(ws), nblk, rows, cols, int(accumulate),
+                           dt(x), _st()), "mk_colsum")
+    return out
+
+
+# -------------------------------------------------------------- pointwise --
+def rope_(x, cos_t, sin_t, pos, heads, hd, inverse=False):
+    """in-place RoPE on x [tokens, heads*hd] (pitched rows allowed)"""
+    lib = _L.load()
+    tokens = x.shape[0]
+    _L.check(lib.mk_rope(_p(x), _p(cos_t), _p(sin_t), _p(pos), tokens, heads, hd, _rowmajor(x),
+                         int(inverse), dt(x), _st()), "mk_rope")
+    return x
+
+
+def swiglu_fwd(g, u):
+    lib = _L.load()
+    a = torch.empty_like(g)
+    _L.check(lib.mk_swiglu_fwd(_p(g), _p(u), _p(a), g.numel(), dt(g), _st()), "mk_swiglu_fwd")
+    return a
+
+
+def swiglu_bwd(g, u, da):
+    lib = _L.load()
+    dg, du = torch.empty_like(g), torch.empty_like(u)
+    _L.check(lib.mk_swiglu_bwd(_p(g), _p(u), _p(da), _p(dg), _p(du), g.numel(), dt(g), _st()),
+             "mk_swiglu_bwd")
+    return dg, du
+
+
+def act_fwd(x, act):
+    lib = _L.load()
+    y = torch.empty_like(x)
+    _L.check(lib.mk_act_fwd(_p(x), _p(y), x.numel(), act, dt(x), _st()), "mk_act_fwd")
+    return y
+
+
+def act_bwd(x_pre, dy, act):
+    lib = _L.load()
+    dx = torch.empty_like(dy)
+    _L.check(lib.mk_act_bwd(_p(x_pre), _p(dy), _p(dx), dy.numel(), act, dt(dy), _st()), "mk_act_bwd")
+    return dx
+
+
+def add(a, b, out=None, period=0):
+    lib = _L.load()
+    if out is None:
+        out = torch.empty_like(a)
+    _L.check(lib.mk_add(_p(a), _p(b), _p(out), a.numel(), period, dt(a), _st()), "mk_add")
+    return out
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    lib = _L.load()
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _L.check(lib.mk_cast(_p(x), dt(x), _p(out), _DT[dtype], x.numel(), _st()), "mk_cast")
+    return out
+
+
+def fill_(x, v):
+    lib = _L.load()
+    _L.check(lib.mk_fill(_p(x), float(v), x.numel(), dt(x), _st()), "mk_fill")
+    return x
+
+
+def embedding_fwd(table, ids, out=None):
+    """out[t, :] = table[ids[t], :]; ids int64 1-D"""
+    lib = _L.load()
+    tokens = ids.numel()
+    vocab, dim = table.shape
+    if out is None:
+        out = torch.empty((tokens, dim), dtype=table.dtype, device=table.device)
+    _L.check(lib.mk_embedding_fwd(_p(table), _p(ids), _p(out), tokens, dim, _rowmajor(out), vocab,
+                                  dt(table), _st()), "mk_embedding_fwd")
+    return out
+
+
+def embedding_bwd_(dtable, dout, ids, padding_idx=-1):
+    """dtable[ids[t]] += dout[t] (deterministic)"""
+    lib = _L.load()
+    vocab, dim = dtable.shape
+    _L.check(lib.mk_embedding_bwd(_p(dout), _rowmajor(dout), _p(ids), _p(dtable), ids.numel(), dim,
+                                  vocab, -1 if padding_idx is None else padding_idx, dt(dtable),
+                                  _st()), "mk_embedding_bwd")
+    return dtable
+
+
+def pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def im2col1d(x, B, C_, T, kw, stride, pad, sb, sc, st, ld_out=None):
+    lib = _L.load()
+    Lout = (T + 2 * pad - kw) // stride + 1
+    K = C_ * kw
+    if ld_out is None:
+        ld_out = pad8(K)
+    out = torch.empty((B * Lout, ld_out), dtype=x.dtype, device=x.device)
+    _L.check(lib.mk_im2col1d(_p(x), _p(out), B, C_, T, kw, stride, pad, Lout, sb, sc, st, ld_out,
+                             dt(x), _st()), "mk_im2col1d")
+    return out, Lout
+
+
+def col2im1d(dcols, B, C_, T, kw, stride, pad, Lout, sb, sc, st, out_shape):
+    lib = _L.load()
+    dx = torch.empty(out_shape, dtype=dcols.dtype, device=dcols.device)
+    _L.check(lib.mk_col2im1d(_p(dcols), _p(dx), B, C_, T, kw, stride, pad, Lout, sb, sc, st,
+                             _rowmajor(dcols), dt(dcols), _st()), "mk_col2im1d")
+    return dx
+
+
+def patchify(img, P):
+    lib = _L.load()
+    B, C_, H, W = img.shape
+    img = img.contiguous()
+    K = C_ * P * P
+    ld = pad8(K)
+    out = torch.empty((B * (H // P) * (W // P), ld), dtype=img.dtype, device=img.device)
+    _L.check(lib.mk_patchify(_p(img), _p(out), B, C_, H, W, P, ld, dt(img), _st()), "mk_patchify")
+    return out
+
+
+def unpatchify(dcols, B, C_, H, W, P):
+    lib = _L.load()
+    dimg = torch.empty((B, C_, H, W), dtype=dcols.dtype, device=dcols.device)
+    _L.check(lib.mk_unpatchify(_p(dcols), _p(dimg), B, C_, H, W, P, _rowmajor(dcols), dt(dcols),
+                               _st()), "mk_unpatchify")
+    return dimg
+
+
+# ---------------------------------------------------------------- softmax --
+def softmax_fwd(scores, nz, heads, Lq, Lk, ld, kmask=None, causal=False, dropout_p=0.0, seed=0,
+                probs=None, want_dropped=False):
+    """scores: buffer of nz*Lq rows with pitch ld.  Returns (probs, probs_dropped|None)."""
+    lib = _L.load()
+    if probs is None:
+        probs = torch.empty_like(scores)
+    pd = torch.empty_like(scores) if (dropout_p > 0.0 and want_dropped) else None
+    _L.check(lib.mk_softmax_fwd(_p(scores), _p(probs), _p(pd), _p(kmask), nz, heads, Lq, Lk, ld,
+                                int(causal), float(dropout_p), int(seed), dt(scores), _st()),
+             "mk_softmax_fwd")
+    return probs, pd
+
+
+def softmax_bwd_(probs, dprobs, nz, Lq, Lk, ld, scale=1.0, dropout_p=0.0, seed=0):
+    lib = _L.load()
+    _L.check(lib.mk_softmax_bwd(_p(probs), _p(dprobs), nz, Lq, Lk, ld, float(scale),
+                                float(dropout_p), int(seed), dt(probs), _st()), "mk_softmax_bwd")
+    return dprobs
+
+
+def cross_entropy(logits, labels, V):
+    """logits [rows, ld>=V] row-major; labels int64 [rows] already shifted.
+    returns (row_loss, row_lse, sum_cnt[2])"""
+    lib = _L.load()
+    rows = logits.shape[0]
+    row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    row_lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    sum_cnt = torch.empty(2, dtype=torch.float32, device=logits.device)
+    _L.check(lib.mk_cross_entropy(_p(logits), _p(labels), _p(row_loss), _p(row_lse), _p(sum_cnt),
+                                  rows, V, _rowmajor(logits), dt(logits), _st()),
+             "mk_cross_entropy")
+    return row_loss, row_lse, sum_cnt
+
+
+def cross_entropy_bwd(logits, labels, row_lse, sum_cnt, V, grad_scale=1.0, out=None):
+    lib = _L.load()
+    rows = logits.shape[0]
+    if out is None:
+        out = torch.empty_like(logits)
+    _L.check(lib.mk_cross_entropy_bwd(_p(logits), _p(out), _p(labels), _p(row_lse), _p(sum_cnt),
+                                      float(grad_scale), rows, V, _rowmajor(logits), dt(logits),
+                                      _st()), "mk_cross_entropy_bwd")
+    return out
+
+
+def adamw_(param, master, m, v, grad, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    lib = _L.load()
+    _L.check(lib.mk_adamw(_p(param), _p(master), _p(m), _p(v), _p(grad), param.numel(), lr, beta1,
+                          beta2, eps, wd, step, grad_scale, dt(param), _st()), "mk_adamw")
