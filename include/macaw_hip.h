@@ -128,6 +128,11 @@ int mk_add(const void* a, const void* b, void* y, int64_t n, int64_t period, int
 int mk_cast(const void* in, int32_t in_dtype, void* out, int32_t out_dtype, int64_t n,
             void* stream);
 int mk_fill(void* p, float v, int64_t n, int32_t dtype, void* stream);
+/* dst[z][r][0:cols] = src[z][r][0:cols] (pitched rows, batch strides; s_src = 0 broadcasts):
+ * the torch.cat / slice / repeat plumbing of modeling.py:974-1046 without eager kernels. */
+int mk_copy2d(const void* src, void* dst, int32_t rows, int32_t cols, int64_t ld_src,
+              int64_t ld_dst, int32_t batch, int64_t s_src, int64_t s_dst, int32_t elem_size,
+              void* stream);
 
 /* Embedding gather (modeling.py:972,979-980): out[t] = table[ids[t]]; ids int64. */
 int mk_embedding_fwd(const void* table, const int64_t* ids, void* out, int32_t tokens,
@@ -181,7 +186,7 @@ int mk_softmax_bwd(const void* probs, void* dprobs, int32_t nz, int32_t Lq, int3
 /* Shifted cross-entropy (modeling.py:600-610). The caller passes labels already shifted
  * (row r predicts labels[r]; -100 = ignore).  row_loss[r] = lse_r - logit[r][label] (0 when
  * ignored), row_lse[r] kept for backward, loss_sum_cnt = {sum of row losses, number of valid
- * rows} (f32[2], reduced deterministically on device; loss = [0]/[1]). */
+ * rows, mean loss, 0} (f32[4], reduced deterministically on device). */
 int mk_cross_entropy(const void* logits, const int64_t* labels, float* row_loss, float* row_lse,
                      float* loss_sum_cnt, int32_t rows, int32_t V, int64_t ld, int32_t dtype,
                      void* stream);
@@ -189,6 +194,7 @@ int mk_cross_entropy(const void* logits, const int64_t* labels, float* row_loss,
  * ignored rows and for pad columns c in [V, ld).  dlogits may alias logits. */
 int mk_cross_entropy_bwd(const void* logits, void* dlogits, const int64_t* labels,
                          const float* row_lse, const float* loss_sum_cnt, float grad_scale,
+                         const float* grad_scale_dev /* optional device scalar multiplied in */,
                          int32_t rows, int32_t V, int64_t ld, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------ optimizer --

@@ -42,6 +42,18 @@ template <> MK_DEV float from_f32<float>(float v) { return v; }
 template <> MK_DEV bf16 from_f32<bf16>(float v) { return (bf16)v; }  // RNE (v_cvt_pk_bf16_f32)
 template <> MK_DEV _Float16 from_f32<_Float16>(float v) { return (_Float16)v; }
 
+// Round-trip through the storage type: the value the eager reference would hold after an
+// op in that dtype.  The bf16 form is done on the bits (RNE) because hipcc folds
+// (float)(__bf16)x back to x under its excess-precision rules.
+template <typename T> MK_DEV float rnd(float v);
+template <> MK_DEV float rnd<float>(float v) { return v; }
+template <> MK_DEV float rnd<bf16>(float v) {
+  uint32_t u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return v;  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return __uint_as_float(u & 0xffff0000u);
+}
+
 // Vector-of-VEC access: VEC elements of T moved as one 16-byte (bf16x8) or
 // 16-byte (float4) transaction.  VecIO<T>::N elements per 16 B.
 template <typename T> struct VecIO;

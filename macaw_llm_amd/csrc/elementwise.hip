@@ -7,7 +7,6 @@
 
 namespace {
 
-template <typename T> MK_DEV float rnd(float v) { return to_f32<T>(from_f32<T>(v)); }
 
 inline int ew_grid(long work_items) {
   long b = (work_items + 255) / 256;
@@ -156,7 +155,8 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const T* table, cons
                                                             int vocab) {
   const long t = blockIdx.x;
   long id = ids[t];
-  if (id < 0 || id >= vocab) id = 0;  // host validates; never fault
+  if (id < 0) return;                 // slot owned by a modality prefix: left untouched
+  if (id >= vocab) id = 0;            // host validates ids; never fault
   const T* src = table + id * dim;
   T* dst = out + t * ld_out;
   constexpr int N = VecIO<T>::N;
@@ -262,6 +262,38 @@ __global__ __launch_bounds__(256) void patchify_kernel(const T* img, T* cols, in
   }
 }
 
+
+// ------------------------------------------------------------------ copy --
+// dst[z][r][0:cols] = src[z][r][0:cols] with independent pitches / batch strides
+// (src batch stride 0 broadcasts).  16-byte vectors when everything is aligned.
+template <int ES>
+__global__ __launch_bounds__(256) void copy2d_kernel(const char* src, char* dst, int rows,
+                                                     long row_bytes, long ld_src, long ld_dst,
+                                                     long s_src, long s_dst, int vec) {
+  src += (long)blockIdx.z * s_src;
+  dst += (long)blockIdx.z * s_dst;
+  if (vec) {
+    const long nv = row_bytes / 16;
+    const long total = (long)rows * nv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      const long r = i / nv, c = i - r * nv;
+      *reinterpret_cast<uint4*>(dst + r * ld_dst + c * 16) =
+          *reinterpret_cast<const uint4*>(src + r * ld_src + c * 16);
+    }
+  } else {
+    const long ne = row_bytes / ES;
+    const long total = (long)rows * ne;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      const long r = i / ne, c = i - r * ne;
+      if (ES == 2)
+        *reinterpret_cast<unsigned short*>(dst + r * ld_dst + c * 2) =
+            *reinterpret_cast<const unsigned short*>(src + r * ld_src + c * 2);
+      else
+        *reinterpret_cast<unsigned*>(dst + r * ld_dst + c * 4) =
+            *reinterpret_cast<const unsigned*>(src + r * ld_src + c * 4);
+    }
+  }
+}
 }  // namespace
 
 #define MK_ST reinterpret_cast<hipStream_t>(stream)
@@ -427,5 +459,28 @@ extern "C" int mk_unpatchify(const void* dcols, void* dimg, int32_t B, int32_t C
   MK_DISPATCH_T(dtype, hipLaunchKernelGGL((patchify_kernel<T, false>), dim3(ew_grid(total)),
                                           dim3(256), 0, MK_ST, (const T*)dimg, (T*)dcols, B, C, H,
                                           W, P, (long)ld_cols));
+  return mk_check_launch();
+}
+
+extern "C" int mk_copy2d(const void* src, void* dst, int32_t rows, int32_t cols, int64_t ld_src,
+                         int64_t ld_dst, int32_t batch, int64_t s_src, int64_t s_dst,
+                         int32_t elem_size, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || batch <= 0) return MK_ERR_BAD_ARG;
+  if (elem_size != 2 && elem_size != 4) return MK_ERR_UNSUPPORTED;
+  const long es = elem_size;
+  const long row_bytes = (long)cols * es;
+  const int vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 &&
+                  (row_bytes % 16 == 0) && ((ld_src * es) % 16 == 0) && ((ld_dst * es) % 16 == 0) &&
+                  ((s_src * es) % 16 == 0) && ((s_dst * es) % 16 == 0);
+  const long work = (long)rows * (vec ? row_bytes / 16 : cols);
+  dim3 grid(ew_grid(work), 1, batch), block(256);
+  if (elem_size == 2)
+    hipLaunchKernelGGL((copy2d_kernel<2>), grid, block, 0, MK_ST, (const char*)src, (char*)dst, rows,
+                       row_bytes, (long)ld_src * es, (long)ld_dst * es, (long)s_src * es,
+                       (long)s_dst * es, vec);
+  else
+    hipLaunchKernelGGL((copy2d_kernel<4>), grid, block, 0, MK_ST, (const char*)src, (char*)dst, rows,
+                       row_bytes, (long)ld_src * es, (long)ld_dst * es, (long)s_src * es,
+                       (long)s_dst * es, vec);
   return mk_check_launch();
 }

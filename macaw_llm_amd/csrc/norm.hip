@@ -10,7 +10,6 @@
 
 namespace {
 
-template <typename T> MK_DEV float rnd(float v) { return to_f32<T>(from_f32<T>(v)); }
 
 // ---------------------------------------------------------------- RMSNorm --
 template <typename T>

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* logits, const int6
     row_loss[row] = lse - to_f32<T>(lr[lab]);
   }
 }
-// Deterministic single-block reduction: out = {sum loss, n_valid}
+// Deterministic single-block reduction: out = {sum loss, n_valid, mean loss, 0}
 __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* row_loss,
                                                         const int64_t* labels, float* out,
                                                         int rows, int V) {
@@ -193,19 +193,20 @@ __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* row_loss,
   }
   s = block_sum<256>(s, red);
   n = block_sum<256>(n, red);
-  if (threadIdx.x == 0) { out[0] = s; out[1] = n; }
+  if (threadIdx.x == 0) { out[0] = s; out[1] = n; out[2] = n > 0.f ? s / n : 0.f; out[3] = 0.f; }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* logits, T* dlogits,
                                                      const int64_t* labels, const float* row_lse,
-                                                     const float* sum_cnt, float grad_scale, int V,
-                                                     long ld) {
+                                                     const float* sum_cnt, float grad_scale,
+                                                     const float* grad_scale_dev, int V, long ld) {
   const long row = blockIdx.x;
   const T* lr = logits + row * ld;
   T* dr = dlogits + row * ld;
   const long lab = labels[row];
   const bool valid = lab >= 0 && lab < V;
   const float n = sum_cnt[1];
+  if (grad_scale_dev) grad_scale *= *grad_scale_dev;
   const float gs = (valid && n > 0.f) ? grad_scale / n : 0.f;
   const float lse = row_lse[row];
   for (int c = threadIdx.x; c < (int)ld; c += 256) {
@@ -318,18 +319,19 @@ extern "C" int mk_cross_entropy(const void* logits, const int64_t* labels, float
 
 extern "C" int mk_cross_entropy_bwd(const void* logits, void* dlogits, const int64_t* labels,
                                     const float* row_lse, const float* loss_sum_cnt,
-                                    float grad_scale, int32_t rows, int32_t V, int64_t ld,
-                                    int32_t dtype, void* stream) {
+                                    float grad_scale, const float* grad_scale_dev, int32_t rows,
+                                    int32_t V, int64_t ld, int32_t dtype, void* stream) {
   if (!logits || !dlogits || !labels || !row_lse || !loss_sum_cnt || rows <= 0 || V <= 0 ||
       ld < V)
     return MK_ERR_BAD_ARG;
   if (dtype == MK_BF16)
     hipLaunchKernelGGL((ce_bwd_kernel<bf16>), dim3(rows), dim3(256), 0, MK_ST, (const bf16*)logits,
-                       (bf16*)dlogits, labels, row_lse, loss_sum_cnt, grad_scale, V, (long)ld);
+                       (bf16*)dlogits, labels, row_lse, loss_sum_cnt, grad_scale, grad_scale_dev, V,
+                       (long)ld);
   else if (dtype == MK_F32)
     hipLaunchKernelGGL((ce_bwd_kernel<float>), dim3(rows), dim3(256), 0, MK_ST,
                        (const float*)logits, (float*)dlogits, labels, row_lse, loss_sum_cnt,
-                       grad_scale, V, (long)ld);
+                       grad_scale, grad_scale_dev, V, (long)ld);
   else return MK_ERR_UNSUPPORTED;
   return mk_check_launch();
 }

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mk_add": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "mk_cast": [_vp, _i32, _vp, _i32, _i64, _vp],
     "mk_fill": [_vp, _f32, _i64, _i32, _vp],
+    "mk_copy2d": [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _vp],
     "mk_embedding_fwd": [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp],
     "mk_embedding_bwd": [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp],
     "mk_im2col1d": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64,
@@ -71,7 +72,7 @@ SIGNATURES = {
                        _vp],
     "mk_softmax_bwd": [_vp, _vp, _i32, _i32, _i32, _i64, _f32, _f32, _u64, _i32, _vp],
     "mk_cross_entropy": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp],
-    "mk_cross_entropy_bwd": [_vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _i64, _i32, _vp],
+    "mk_cross_entropy_bwd": [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i64, _i32, _vp],
     "mk_adamw": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _i32,
                  _vp],
 }

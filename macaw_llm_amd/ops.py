@@ -270,6 +270,15 @@ def fill_(x, v):
     return x
 
 
+def copy2d(src, dst, rows, cols, ld_src, ld_dst, batch=1, s_src=0, s_dst=0, src_off=0, dst_off=0):
+    """strided 2-D (batched) copy; offsets/strides in elements"""
+    lib = _L.load()
+    es = src.element_size()
+    _L.check(lib.mk_copy2d(_p(src) + src_off * es, _p(dst) + dst_off * es, rows, cols, ld_src, ld_dst,
+                           batch, s_src, s_dst, es, _st()), "mk_copy2d")
+    return dst
+
+
 def embedding_fwd(table, ids, out=None):
     """out[t, :] = table[ids[t], :]; ids int64 1-D"""
     lib = _L.load()
@@ -363,20 +372,22 @@ def cross_entropy(logits, labels, V):
     rows = logits.shape[0]
     row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
     row_lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
-    sum_cnt = torch.empty(2, dtype=torch.float32, device=logits.device)
+    sum_cnt = torch.empty(4, dtype=torch.float32, device=logits.device)
     _L.check(lib.mk_cross_entropy(_p(logits), _p(labels), _p(row_loss), _p(row_lse), _p(sum_cnt),
                                   rows, V, _rowmajor(logits), dt(logits), _st()),
              "mk_cross_entropy")
     return row_loss, row_lse, sum_cnt
 
 
-def cross_entropy_bwd(logits, labels, row_lse, sum_cnt, V, grad_scale=1.0, out=None):
+def cross_entropy_bwd(logits, labels, row_lse, sum_cnt, V, grad_scale=1.0, out=None,
+                      grad_scale_dev=None):
     lib = _L.load()
     rows = logits.shape[0]
     if out is None:
         out = torch.empty_like(logits)
     _L.check(lib.mk_cross_entropy_bwd(_p(logits), _p(out), _p(labels), _p(row_lse), _p(sum_cnt),
-                                      float(grad_scale), rows, V, _rowmajor(logits), dt(logits),
+                                      float(grad_scale), _p(grad_scale_dev), rows, V,
+                                      _rowmajor(logits), dt(logits),
                                       _st()), "mk_cross_entropy_bwd")
     return out
 

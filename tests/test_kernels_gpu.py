@@ -1,0 +1,394 @@
+"""GPU parity tests of every C-ABI kernel against the CPU oracle (plain fp32 torch ops /
+oracle.restate functions) on the same seeded inputs.  Tolerances are written per test:
+  f32 kernels  : rtol 2e-5 (exact-f32 MFMA / fp32 VALU, only summation order differs)
+  bf16 kernels : inputs are bf16-rounded on both sides, fp32 accumulation; the only error
+                 is the final bf16 rounding (rel 2^-8 = 3.9e-3) -> rtol 8e-3 + small atol.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from macaw_llm_amd import ops  # noqa: E402
+from oracle import restate  # noqa: E402
+
+
+def _tol(dtype):
+    return dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=8e-3, atol=8e-3)
+
+
+def _rand(shape, dtype, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def _close(got, ref, dtype, scale=1.0, what=""):
+    tol = _tol(dtype)
+    got = got.float().cpu()
+    ref = ref.float()
+    err = (got - ref).abs().max().item()
+    lim = tol["atol"] * scale + tol["rtol"] * ref.abs().max().item()
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    assert err <= lim, f"{what}: max abs err {err:.3e} > {lim:.3e}"
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("a_red,b_red", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 107, 72), (37, 250, 1000),
+                                   (6, 9, 4)])
+def test_gemm_layouts(dev, dtype, a_red, b_red, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = _rand((K, M) if a_red else (M, K), dtype, g)
+    B = _rand((K, N) if b_red else (N, K), dtype, g)
+    Al = A.float().t() if a_red else A.float()
+    Bl = B.float().t() if b_red else B.float()
+    ref = Al @ Bl.t()
+    C = torch.empty((M, N), dtype=dtype, device=dev)
+    Ad, Bd = A.to(dev), B.to(dev)
+    ops.gemm_raw(Ad, Bd, C, M, N, K, Ad.stride(0), Bd.stride(0), N, a_red=a_red, b_red=b_red)
+    _close(C, ref, dtype, scale=math.sqrt(K), what=f"gemm {M}x{N}x{K} {a_red}{b_red}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(dev, dtype):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 192, 200, 136
+    x, W = _rand((M, K), dtype, g), _rand((N, K), dtype, g, 0.1)
+    bias, R, C0 = _rand((N,), dtype, g), _rand((M, N), dtype, g), _rand((M, N), dtype, g)
+    xd, Wd, bd, Rd = x.to(dev), W.to(dev), bias.to(dev), R.to(dev)
+    base = x.float() @ W.float().t()
+    for act, fn in [(0, lambda t: t), (1, F.gelu), (2, restate.quick_gelu)]:
+        out = ops.linear_fwd(xd, Wd, bias=bd, act=act, residual=Rd, alpha=0.5)
+        ref = fn(0.5 * base + bias.float()) + R.float()
+        _close(out, ref, dtype, scale=4.0, what=f"epilogue act={act}")
+    # accumulate into existing C
+    Cd = C0.to(dev).clone()
+    ops.gemm_raw(xd, Wd, Cd, M, N, K, K, K, N, accumulate=True)
+    _close(Cd, base + C0.float(), dtype, scale=4.0, what="accumulate")
+    # per-row bias (bias_mode 2)
+    brow = _rand((M,), dtype, g).to(dev)
+    Cd = torch.empty((M, N), dtype=dtype, device=dev)
+    ops.gemm_raw(xd, Wd, Cd, M, N, K, K, K, N, bias=brow, bias_mode=2)
+    _close(Cd, base + brow.float().cpu()[:, None], dtype, scale=4.0, what="row bias")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_batched_strided_pitched(dev, dtype):
+    """attention-shaped batched GEMM: scores[b,h] = q[b,h] k[b,h]^T read straight out of the
+    [B*S, H*hd] projection buffers, written into a pitched [B,H,S,Sp] buffer."""
+    g = torch.Generator().manual_seed(9)
+    Bn, H, S, hd = 2, 3, 50, 16
+    D = H * hd
+    q, k = _rand((Bn * S, D), dtype, g), _rand((Bn * S, D), dtype, g)
+    qd, kd = q.to(dev), k.to(dev)
+    Sp = 56
+    sc = torch.zeros((Bn, H, S, Sp), dtype=dtype, device=dev)
+    ops.gemm_raw(qd, kd, sc, S, S, hd, D, D, Sp, nb1=Bn, nb2=H, sA=(S * D, hd), sB=(S * D, hd),
+                 sC=(H * S * Sp, S * Sp), alpha=0.25)
+    qf = q.float().view(Bn, S, H, hd).transpose(1, 2)
+    kf = k.float().view(Bn, S, H, hd).transpose(1, 2)
+    ref = 0.25 * qf @ kf.transpose(-1, -2)
+    _close(sc[..., :S], ref, dtype, scale=4.0, what="batched qk")
+    assert (sc[..., S:] == 0).all()  # pad columns untouched
+    # P @ V with V consumed red-major from the same projection layout, output into [B*S, D]
+    p = torch.softmax(ref, -1).to(dtype)
+    pd = torch.zeros((Bn, H, S, Sp), dtype=dtype, device=dev)
+    pd[..., :S] = p.to(dev)
+    v = _rand((Bn * S, D), dtype, g)
+    vd = v.to(dev)
+    ctx = torch.empty((Bn * S, D), dtype=dtype, device=dev)
+    ops.gemm_raw(pd, vd, ctx, S, hd, S, Sp, D, D, b_red=True, nb1=Bn, nb2=H,
+                 sA=(H * S * Sp, S * Sp), sB=(S * D, hd), sC=(S * D, hd))
+    vf = v.float().view(Bn, S, H, hd).transpose(1, 2)
+    refc = (p.float() @ vf).transpose(1, 2).reshape(Bn * S, D)
+    _close(ctx, refc, dtype, scale=1.0, what="batched pv")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_grads(dev, dtype):
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 320, 264, 200
+    dy, W, x = _rand((M, N), dtype, g), _rand((N, K), dtype, g, 0.1), _rand((M, K), dtype, g)
+    dx = ops.linear_dx(dy.to(dev), W.to(dev))
+    _close(dx, dy.float() @ W.float(), dtype, scale=2.0, what="dx")
+    dw = ops.linear_dw(dy.to(dev), x.to(dev))
+    _close(dw, dy.float().t() @ x.float(), dtype, scale=math.sqrt(M), what="dw")
+
+
+@pytest.mark.parametrize("es", [2, 4])
+def test_transpose(dev, es):
+    dtype = torch.bfloat16 if es == 2 else torch.float32
+    x = torch.randn(3, 70, 130).to(dtype)
+    out = ops.transpose(x.to(dev))
+    assert torch.equal(out.cpu(), x.transpose(1, 2).contiguous())
+    x2 = x[0]
+    assert torch.equal(ops.transpose(x2.to(dev)).cpu(), x2.t().contiguous())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,cols", [(37, 128), (16, 4096), (5, 8)])
+def test_rmsnorm(dev, dtype, rows, cols):
+    g = torch.Generator().manual_seed(rows + cols)
+    x, res, w = _rand((rows, cols), dtype, g), _rand((rows, cols), dtype, g), (1 + 0.1 * torch.randn(cols, generator=g)).to(dtype)
+    h, y, rstd = ops.rmsnorm_fwd(x.to(dev), w.to(dev), 1e-6, res=res.to(dev))
+    href = x + res  # in dtype, as the eager reference does
+    assert torch.equal(h.cpu(), href)
+    yref = restate.rms_norm(href, w, 1e-6)
+    _close(y, yref, dtype, what="rmsnorm y")
+    # no-residual form
+    h2, y2, _ = ops.rmsnorm_fwd(x.to(dev), w.to(dev), 1e-6)
+    _close(y2, restate.rms_norm(x, w, 1e-6), dtype, what="rmsnorm y (no res)")
+    # backward vs autograd of the fp32 restatement
+    hf = href.float().requires_grad_(True)
+    wf = w.float().requires_grad_(True)
+    dy, dres = _rand((rows, cols), dtype, g), _rand((rows, cols), dtype, g)
+    restate.rms_norm(hf, wf, 1e-6).backward(dy.float())
+    dx, dw = ops.rmsnorm_bwd(dy.to(dev), h, w.to(dev), rstd, dres=dres.to(dev))
+    _close(dx, hf.grad + dres.float(), dtype, scale=2.0, what="rmsnorm dx")
+    _close(dw, wf.grad, dtype, scale=math.sqrt(rows), what="rmsnorm dw")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,cols", [(50, 64), (9, 1024), (3, 20)])
+def test_layernorm(dev, dtype, rows, cols):
+    g = torch.Generator().manual_seed(rows * cols)
+    x = _rand((rows, cols), dtype, g)
+    w, b = (1 + 0.1 * torch.randn(cols, generator=g)).to(dtype), (0.1 * torch.randn(cols, generator=g)).to(dtype)
+    y, mean, rstd = ops.layernorm_fwd(x.to(dev), w.to(dev), b.to(dev), 1e-5)
+    xf, wf, bf = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    yref = F.layer_norm(xf, (cols,), wf, bf, 1e-5)
+    _close(y, yref.detach(), dtype, what="layernorm y")
+    dy, dres = _rand((rows, cols), dtype, g), _rand((rows, cols), dtype, g)
+    yref.backward(dy.float())
+    dx, dw, db = ops.layernorm_bwd(dy.to(dev), x.to(dev), w.to(dev), mean, rstd, dres=dres.to(dev))
+    _close(dx, xf.grad + dres.float(), dtype, scale=2.0, what="layernorm dx")
+    _close(dw, wf.grad, dtype, scale=math.sqrt(rows), what="layernorm dw")
+    _close(db, bf.grad, dtype, scale=math.sqrt(rows), what="layernorm db")
+    _close(ops.colsum(dy.to(dev)), dy.float().sum(0), dtype, scale=math.sqrt(rows), what="colsum")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd", [128, 32, 8])
+def test_rope(dev, dtype, hd):
+    g = torch.Generator().manual_seed(hd)
+    Bn, S, H = 2, 7, 3
+    cos, sin = restate.rotary_tables(hd, 64)
+    cos, sin = cos.to(dtype), sin.to(dtype)
+    q, k = _rand((Bn, S, H, hd), dtype, g), _rand((Bn, S, H, hd), dtype, g)
+    pos = torch.arange(S).repeat(Bn, 1)
+    qr, kr = restate.apply_rope(q.transpose(1, 2), k.transpose(1, 2), cos, sin, pos)
+    qd = q.reshape(Bn * S, H * hd).to(dev).clone()
+    posd = pos.reshape(-1).to(torch.int32).to(dev)
+    ops.rope_(qd, cos.to(dev), sin.to(dev), posd, H, hd)
+    got = qd.view(Bn, S, H, hd).transpose(1, 2).cpu()
+    if dtype == torch.bfloat16:  # same rounding points as the eager bf16 reference: bit-exact
+        nbad = (got != qr).sum().item()
+        assert nbad == 0, (nbad, got.numel(), (got.float() - qr.float()).abs().max().item())
+    else:
+        _close(got, qr, dtype, what="rope")
+    # inverse rotation undoes it (orthogonal): fp32 only, to rounding
+    if dtype == torch.float32:
+        ops.rope_(qd, cos.to(dev), sin.to(dev), posd, H, hd, inverse=True)
+        _close(qd.view(Bn, S, H, hd), q, dtype, what="rope inverse")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_swiglu_act_add_cast(dev, dtype):
+    g = torch.Generator().manual_seed(3)
+    n = (33, 352)
+    gt, u, da = _rand(n, dtype, g), _rand(n, dtype, g), _rand(n, dtype, g)
+    a = ops.swiglu_fwd(gt.to(dev), u.to(dev))
+    gf, uf = gt.float().clone().requires_grad_(True), u.float().clone().requires_grad_(True)
+    ref = F.silu(gf) * uf
+    _close(a, ref.detach(), dtype, what="swiglu")
+    ref.backward(da.float())
+    dg, du = ops.swiglu_bwd(gt.to(dev), u.to(dev), da.to(dev))
+    _close(dg, gf.grad, dtype, scale=2.0, what="swiglu dg")
+    _close(du, uf.grad, dtype, scale=2.0, what="swiglu du")
+    for act, fn in [(1, F.gelu), (2, restate.quick_gelu)]:
+        xf = gt.float().clone().requires_grad_(True)
+        yref = fn(xf)
+        _close(ops.act_fwd(gt.to(dev), act), yref.detach(), dtype, what=f"act{act}")
+        yref.backward(da.float())
+        _close(ops.act_bwd(gt.to(dev), da.to(dev), act), xf.grad, dtype, scale=2.0, what=f"act{act} bwd")
+    _close(ops.add(gt.to(dev), u.to(dev)), gt.float() + u.float(), dtype, what="add")
+    row = _rand((352,), dtype, g)
+    _close(ops.add(gt.to(dev), row.to(dev), period=352), gt.float() + row.float(), dtype, what="add bcast")
+    h16 = torch.randn(1000).half()
+    assert torch.equal(ops.cast(h16.to(dev), dtype).cpu(), h16.to(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embedding(dev, dtype):
+    g = torch.Generator().manual_seed(17)
+    V, D = 107, 128
+    table = _rand((V, D), dtype, g)
+    ids = torch.randint(0, V, (40,), generator=g)
+    ids[5] = ids[9] = ids[33] = 7  # duplicates
+    ids[2] = 0                      # padding_idx row
+    out = ops.embedding_fwd(table.to(dev), ids.to(dev))
+    assert torch.equal(out.cpu(), table[ids])
+    dout = _rand((40, D), dtype, g)
+    dt0 = _rand((V, D), dtype, g)
+    dtab = dt0.to(dev).clone()
+    ops.embedding_bwd_(dtab, dout.to(dev), ids.to(dev), padding_idx=0)
+    ref = dt0.float().clone()
+    for t in range(40):
+        if ids[t] != 0:
+            ref[ids[t]] += dout[t].float()
+    _close(dtab, ref, dtype, scale=2.0, what="embedding bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_im2col_conv1d(dev, dtype):
+    """Conv1d == im2col + GEMM for the three geometries on the path: Whisper conv1 (k3,p1,
+    channels-first input), conv2 (k3,s2,p1, channels-last input) and project_* (k>stride)."""
+    g = torch.Generator().manual_seed(23)
+    Bn = 2
+    # channels-first input [B, C, T]
+    C_, T, O = 10, 40, 24
+    x = _rand((Bn, C_, T), dtype, g)
+    W, b = _rand((O, C_, 3), dtype, g, 0.2), _rand((O,), dtype, g)
+    cols, Lout = ops.im2col1d(x.to(dev), Bn, C_, T, 3, 1, 1, C_ * T, T, 1)
+    Wp = torch.zeros((O, cols.shape[1]), dtype=dtype)
+    Wp[:, : C_ * 3] = W.reshape(O, -1)
+    y = ops.linear_fwd(cols, Wp.to(dev), bias=b.to(dev))
+    ref = F.conv1d(x.float(), W.float(), b.float(), padding=1).transpose(1, 2).reshape(Bn * Lout, O)
+    _close(y, ref, dtype, scale=2.0, what="conv k3 p1")
+    # channels-last input [B, T, C], stride 2
+    xl = _rand((Bn, T, C_), dtype, g)
+    cols, Lout = ops.im2col1d(xl.to(dev), Bn, C_, T, 3, 2, 1, T * C_, 1, C_)
+    y = ops.linear_fwd(cols, Wp.to(dev), bias=b.to(dev))
+    ref = F.conv1d(xl.float().transpose(1, 2), W.float(), b.float(), stride=2, padding=1).transpose(1, 2).reshape(Bn * Lout, O)
+    _close(y, ref, dtype, scale=2.0, what="conv k3 s2 p1")
+    # overlapping windows k=6 s=5 (project_image-like) + adjoint
+    W6 = _rand((O, C_, 6), dtype, g, 0.2)
+    cols, Lout = ops.im2col1d(xl.to(dev), Bn, C_, T, 6, 5, 0, T * C_, 1, C_)
+    assert Lout == (T - 6) // 5 + 1
+    Wp6 = torch.zeros((O, cols.shape[1]), dtype=dtype)
+    Wp6[:, : C_ * 6] = W6.reshape(O, -1)
+    y = ops.linear_fwd(cols, Wp6.to(dev))
+    xr = xl.float().requires_grad_(True)
+    ref = F.conv1d(xr.transpose(1, 2), W6.float(), stride=5).transpose(1, 2).reshape(Bn * Lout, O)
+    _close(y, ref.detach(), dtype, scale=2.0, what="conv k6 s5")
+    dy = _rand((Bn * Lout, O), dtype, g)
+    ref.backward(dy.float())
+    dcols = ops.linear_dx(dy.to(dev), Wp6.to(dev))
+    dx = ops.col2im1d(dcols, Bn, C_, T, 6, 5, 0, Lout, T * C_, 1, C_, (Bn, T, C_))
+    _close(dx, xr.grad, dtype, scale=2.0, what="col2im")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_patchify(dev, dtype):
+    g = torch.Generator().manual_seed(29)
+    Bn, P, Hh, O = 2, 14, 56, 32
+    img = _rand((Bn, 3, Hh, Hh), dtype, g)
+    W = _rand((O, 3, P, P), dtype, g, 0.05)
+    cols = ops.patchify(img.to(dev), P)
+    assert cols.shape == (Bn * 16, 592) and (cols[:, 588:] == 0).all()
+    Wp = torch.zeros((O, 592), dtype=dtype)
+    Wp[:, :588] = W.reshape(O, -1)
+    y = ops.linear_fwd(cols, Wp.to(dev))
+    ref = F.conv2d(img.float(), W.float(), stride=P).flatten(2).transpose(1, 2).reshape(Bn * 16, O)
+    _close(y, ref, dtype, scale=2.0, what="patch embed")
+    back = ops.unpatchify(cols, Bn, 3, Hh, Hh, P)
+    assert torch.equal(back.cpu(), img)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Lq,Lk,causal", [(29, 29, True), (6, 109, False), (5, 1500, False), (3, 2100, False)])
+def test_softmax_fwd_bwd(dev, dtype, Lq, Lk, causal):
+    g = torch.Generator().manual_seed(Lq * Lk)
+    Bn, H = 2, 3
+    ld = (Lk + 7) // 8 * 8
+    s = _rand((Bn, H, Lq, Lk), dtype, g, 2.0)
+    kmask = torch.ones(Bn, Lk, dtype=torch.int32)
+    if causal:
+        kmask[1, -4:] = 0  # right padding on sample 1
+    buf = torch.zeros((Bn, H, Lq, ld), dtype=dtype, device=dev)
+    buf[..., :Lk] = s.to(dev)
+    probs, _ = ops.softmax_fwd(buf, Bn * H, H, Lq, Lk, ld, kmask=kmask.to(dev), causal=causal)
+    # reference masking semantics (modeling.py:205-214)
+    sf = s.clone()
+    if causal:
+        m = restate.decoder_mask(kmask, Bn, Lq, dtype, torch.device("cpu"))
+        sf = torch.max(sf + m, torch.tensor(torch.finfo(dtype).min, dtype=dtype))
+    pref = torch.softmax(sf.float(), -1)
+    _close(probs[..., :Lk], pref, dtype, what="softmax")
+    # backward
+    dP = _rand((Bn, H, Lq, Lk), dtype, g)
+    pf = probs[..., :Lk].float().cpu()
+    dS_ref = pf * (dP.float() - (dP.float() * pf).sum(-1, keepdim=True)) * 0.125
+    dbuf = torch.zeros_like(buf)
+    dbuf[..., :Lk] = dP.to(dev)
+    ops.softmax_bwd_(probs, dbuf, Bn * H, Lq, Lk, ld, scale=0.125)
+    _close(dbuf[..., :Lk], dS_ref, dtype, what="softmax bwd")
+
+
+def test_softmax_dropout_statistics_and_consistency(dev):
+    """dropout: kept fraction ~ 1-p, kept values scaled by 1/(1-p), and the backward kernel
+    regenerates exactly the forward mask."""
+    dtype = torch.float32
+    Bn, H, Lq, Lk = 1, 4, 64, 2000
+    g = torch.Generator().manual_seed(1)
+    s = _rand((Bn, H, Lq, Lk), dtype, g).to(dev)
+    p = 0.1
+    probs, pd = ops.softmax_fwd(s, Bn * H, H, Lq, Lk, Lk, dropout_p=p, seed=1234, want_dropped=True)
+    keep = pd != 0
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < 5e-3, frac
+    torch.testing.assert_close(pd[keep], probs[keep] / (1 - p), rtol=1e-6, atol=0)
+    dP = _rand((Bn, H, Lq, Lk), dtype, g).to(dev)
+    gref = torch.where(keep, dP / (1 - p), torch.zeros_like(dP))
+    dS_ref = probs * (gref - (gref * probs).sum(-1, keepdim=True))
+    dS = ops.softmax_bwd_(probs, dP.clone(), Bn * H, Lq, Lk, Lk, dropout_p=p, seed=1234)
+    torch.testing.assert_close(dS, dS_ref, rtol=1e-4, atol=1e-7)
+    # a different seed gives a different mask
+    _, pd2 = ops.softmax_fwd(s, Bn * H, H, Lq, Lk, Lk, dropout_p=p, seed=99, want_dropped=True)
+    assert ((pd2 != 0) != keep).any()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cross_entropy(dev, dtype):
+    g = torch.Generator().manual_seed(31)
+    rows, V, ld = 58, 107, 112
+    logits = _rand((rows, V), dtype, g, 2.0)
+    labels = torch.randint(0, V, (rows,), generator=g)
+    labels[::5] = -100
+    buf = torch.full((rows, ld), 7.0, dtype=dtype, device=dev)  # garbage in the pad columns
+    buf[:, :V] = logits.to(dev)
+    row_loss, row_lse, sc = ops.cross_entropy(buf, labels.to(dev), V)
+    lf = logits.float().requires_grad_(True)
+    ref = F.cross_entropy(lf, labels)
+    loss = (sc[0] / sc[1]).item()
+    assert abs(loss - ref.item()) <= 2e-5 * abs(ref.item()) + 1e-6, (loss, ref.item())
+    ref.backward()
+    dl = ops.cross_entropy_bwd(buf, labels.to(dev), row_lse, sc, V, grad_scale=1.0)
+    tol = 1e-6 if dtype == torch.float32 else 2e-4
+    assert (dl[:, :V].float().cpu() - lf.grad).abs().max().item() <= tol
+    assert (dl[:, V:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_adamw(dev, dtype):
+    g = torch.Generator().manual_seed(37)
+    n = 5000
+    w0 = torch.randn(n, generator=g)
+    p_ref = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.AdamW([p_ref], lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    param = w0.to(dtype).to(dev)
+    master = w0.to(dev).clone()
+    m = torch.zeros(n, device=dev)
+    v = torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g).to(dtype)
+        p_ref.grad = grad.float()
+        opt.step()
+        ops.adamw_(param, master, m, v, grad.to(dev), 3e-3, 0.9, 0.95, 1e-8, 0.1, step)
+    torch.testing.assert_close(master.cpu(), p_ref.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(param.cpu(), master.cpu().to(dtype))
