@@ -1,0 +1,730 @@
+"""Layer-level forward/backward engine for the Macaw-LLM hot path.
+
+Each autograd.Function here is one *block* of the reference graph (a LLaMA decoder layer,
+a CLIP/Whisper encoder layer, an nn.MultiheadAttention, the lm_head+loss, the multimodal
+prefix assembly) whose forward AND backward are hand-orchestrated sequences of the gfx950
+kernels in csrc/ (through ops.py).  PyTorch autograd only chains these blocks; it never
+differentiates an eager op on the hot path, and residual / fan-out gradient sums are fused
+into our kernels (rmsnorm/layernorm `dres`, GEMM `accumulate`).
+
+Attention is formulated as batched MFMA GEMMs + the softmax kernel (scores are written in
+the activation dtype, softmax runs in fp32: the reference's rounding points,
+modeling.py:197-215).  At the sequence lengths of BASELINE cfg 2/3 (S = 136/144) the score
+tensor is ~42 MB per layer; a fused flash kernel for S = 2048 (cfg 4) is a later row.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import ops
+
+pad8 = ops.pad8
+
+
+# =========================================================================
+# attention core on strided buffers
+# =========================================================================
+class TDesc:
+    """A [rows, heads*hd]-style operand inside a bigger buffer: element offset of
+    (batch b, head h) = off + b*bs + h*hd; row pitch ld."""
+    __slots__ = ("t", "ld", "bs", "off")
+
+    def __init__(self, t, ld, bs, off=0):
+        self.t, self.ld, self.bs, self.off = t, ld, bs, off
+
+
+def attention_fwd(q: TDesc, k: TDesc, v: TDesc, o: TDesc, B, H, Lq, Lk, hd, scale, kmask=None,
+                  causal=False, p=0.0, seed=0):
+    """o[b,h] = dropout(softmax(scale * q[b,h] k[b,h]^T + mask)) v[b,h].
+    Returns (probs, probs_dropped|None) with rows [B*H*Lq, pad8(Lk)]."""
+    Lp = pad8(Lk)
+    dev, dtype = q.t.device, q.t.dtype
+    scores = torch.empty((B * H * Lq, Lp), dtype=dtype, device=dev)
+    ops.gemm_raw(q.t, k.t, scores, Lq, Lk, hd, q.ld, k.ld, Lp, nb1=B, nb2=H, sA=(q.bs, hd),
+                 sB=(k.bs, hd), sC=(H * Lq * Lp, Lq * Lp), a_off=q.off, b_off=k.off, alpha=scale)
+    probs, pd = ops.softmax_fwd(scores, B * H, H, Lq, Lk, Lp, kmask=kmask, causal=causal,
+                                dropout_p=p, seed=seed, probs=scores, want_dropped=p > 0.0)
+    pa = pd if pd is not None else probs
+    ops.gemm_raw(pa, v.t, o.t, Lq, hd, Lk, Lp, v.ld, o.ld, b_red=True, nb1=B, nb2=H,
+                 sA=(H * Lq * Lp, Lq * Lp), sB=(v.bs, hd), sC=(o.bs, hd), b_off=v.off, c_off=o.off)
+    return probs, pd
+
+
+def attention_bwd(do: TDesc, q: TDesc, k: TDesc, v: TDesc, probs, pd, dq: TDesc, dk: TDesc,
+                  dv: TDesc, B, H, Lq, Lk, hd, scale, p=0.0, seed=0):
+    """Given do = dL/do, writes dq, dk, dv (same layouts as q, k, v)."""
+    Lp = pad8(Lk)
+    dP = torch.empty_like(probs)
+    sP = (H * Lq * Lp, Lq * Lp)
+    # dP = do v^T
+    ops.gemm_raw(do.t, v.t, dP, Lq, Lk, hd, do.ld, v.ld, Lp, nb1=B, nb2=H, sA=(do.bs, hd),
+                 sB=(v.bs, hd), sC=sP, a_off=do.off, b_off=v.off)
+    # dv = P_dropped^T do      (both operands reduction-major: no transposes)
+    pa = pd if pd is not None else probs
+    ops.gemm_raw(pa, do.t, dv.t, Lk, hd, Lq, Lp, do.ld, dv.ld, a_red=True, b_red=True, nb1=B, nb2=H,
+                 sA=sP, sB=(do.bs, hd), sC=(dv.bs, hd), b_off=do.off, c_off=dv.off)
+    # dS = softmax'(P, dP) * scale   (in place)
+    ops.softmax_bwd_(probs, dP, B * H, Lq, Lk, Lp, scale=scale, dropout_p=p, seed=seed)
+    # dq = dS k ; dk = dS^T q
+    ops.gemm_raw(dP, k.t, dq.t, Lq, hd, Lk, Lp, k.ld, dq.ld, b_red=True, nb1=B, nb2=H, sA=sP,
+                 sB=(k.bs, hd), sC=(dq.bs, hd), b_off=k.off, c_off=dq.off)
+    ops.gemm_raw(dP, q.t, dk.t, Lk, hd, Lq, Lp, q.ld, dk.ld, a_red=True, b_red=True, nb1=B, nb2=H,
+                 sA=sP, sB=(q.bs, hd), sC=(dk.bs, hd), b_off=q.off, c_off=dk.off)
+
+
+def _c2(x: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """view as contiguous [rows, cols] (copy through our kernel when needed)"""
+    if x.is_contiguous():
+        return x.view(rows, cols)
+    src = x.reshape(rows, cols) if x.dim() != 2 else x
+    if src.stride(1) == 1:
+        out = torch.empty((rows, cols), dtype=x.dtype, device=x.device)
+        return ops.copy2d(src, out, rows, cols, src.stride(0), cols)
+    raise ops.MacawHipError(f"unsupported layout {tuple(x.shape)} {x.stride()}")
+
+
+# =========================================================================
+# LLaMA decoder layer  (modeling.py:234-299)
+# =========================================================================
+class LlamaLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kmask, pos, cos, sin, n_heads, eps, wq, wk, wv, wo, wg, wu, wd, ln1, ln2):
+        B, S, D = x.shape
+        M, H, hd = B * S, n_heads, D // n_heads
+        x2 = _c2(x, M, D)
+        _, y1, rstd1 = ops.rmsnorm_fwd(x2, ln1, eps)
+        q, k, v = ops.linear_fwd(y1, wq), ops.linear_fwd(y1, wk), ops.linear_fwd(y1, wv)
+        ops.rope_(q, cos, sin, pos, H, hd)
+        ops.rope_(k, cos, sin, pos, H, hd)
+        att = torch.empty((M, D), dtype=x.dtype, device=x.device)
+        probs, _ = attention_fwd(TDesc(q, D, S * D), TDesc(k, D, S * D), TDesc(v, D, S * D),
+                                 TDesc(att, D, S * D), B, H, S, S, hd, 1.0 / math.sqrt(hd),
+                                 kmask=kmask, causal=True)
+        h1 = ops.linear_fwd(att, wo, residual=x2)
+        _, y2, rstd2 = ops.rmsnorm_fwd(h1, ln2, eps)
+        g, u = ops.linear_fwd(y2, wg), ops.linear_fwd(y2, wu)
+        a = ops.swiglu_fwd(g, u)
+        out = ops.linear_fwd(a, wd, residual=h1)
+        ctx.save_for_backward(x2, rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, a, pos, cos,
+                              sin, wq, wk, wv, wo, wg, wu, wd, ln1, ln2)
+        ctx.dims = (B, S, D, H, hd)
+        return out.view(B, S, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x2, rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, a, pos, cos, sin, wq, wk, wv, wo,
+         wg, wu, wd, ln1, ln2) = ctx.saved_tensors
+        B, S, D, H, hd = ctx.dims
+        M = B * S
+        need = ctx.needs_input_grad
+        dout2 = _c2(dout, M, D)
+        # ---- MLP
+        da = ops.linear_dx(dout2, wd)
+        dwd = ops.linear_dw(dout2, a) if need[13] else None
+        dg, du = ops.swiglu_bwd(g, u, da)
+        del da
+        dy2 = ops.linear_dx(dg, wg)
+        ops.linear_dx(du, wu, out=dy2, accumulate=True)
+        dwg = ops.linear_dw(dg, y2) if need[11] else None
+        dwu = ops.linear_dw(du, y2) if need[12] else None
+        del dg, du
+        dh1, dln2 = ops.rmsnorm_bwd(dy2, h1, ln2, rstd2, dres=dout2)
+        # ---- attention
+        datt = ops.linear_dx(dh1, wo)
+        dwo = ops.linear_dw(dh1, att) if need[10] else None
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        d = lambda t: TDesc(t, D, S * D)  # noqa: E731
+        attention_bwd(d(datt), d(q), d(k), d(v), probs, None, d(dq), d(dk), d(dv), B, H, S, S, hd,
+                      1.0 / math.sqrt(hd))
+        ops.rope_(dq, cos, sin, pos, H, hd, inverse=True)
+        ops.rope_(dk, cos, sin, pos, H, hd, inverse=True)
+        dy1 = ops.linear_dx(dq, wq)
+        ops.linear_dx(dk, wk, out=dy1, accumulate=True)
+        ops.linear_dx(dv, wv, out=dy1, accumulate=True)
+        dwq = ops.linear_dw(dq, y1) if need[7] else None
+        dwk = ops.linear_dw(dk, y1) if need[8] else None
+        dwv = ops.linear_dw(dv, y1) if need[9] else None
+        dx, dln1 = ops.rmsnorm_bwd(dy1, x2, ln1, rstd1, dres=dh1)
+        return (dx.view(B, S, D), None, None, None, None, None, None, dwq, dwk, dwv, dwo, dwg, dwu,
+                dwd, dln1 if need[14] else None, dln2 if need[15] else None)
+
+
+# =========================================================================
+# final norm + lm_head + shifted cross-entropy  (modeling.py:508,597-610)
+# =========================================================================
+class LMHeadLossFn(torch.autograd.Function):
+    """returns (loss[1] f32, logits view [B,S,V] on a pitched buffer)."""
+
+    @staticmethod
+    def forward(ctx, h, norm_w, lm_w, shift_labels, eps):
+        B, S, D = h.shape
+        M, V = B * S, lm_w.shape[0]
+        h2 = _c2(h, M, D)
+        _, y, rstd = ops.rmsnorm_fwd(h2, norm_w, eps)
+        ldv = (V + 63) // 64 * 64
+        buf = torch.empty((M, ldv), dtype=h.dtype, device=h.device)
+        ops.gemm_raw(y, lm_w, buf, M, V, D, D, D, ldv)
+        logits = buf.view(B, S, ldv)[:, :, :V]
+        if shift_labels is None:
+            ctx.has_loss = False
+            ctx.save_for_backward(h2, rstd, y, norm_w, lm_w)
+            ctx.dims = (B, S, D, V, ldv)
+            loss = torch.zeros(1, dtype=torch.float32, device=h.device)
+            ctx.mark_non_differentiable(loss)
+            return loss, logits
+        _, row_lse, sum_cnt = ops.cross_entropy(buf, shift_labels, V)
+        ctx.has_loss = True
+        ctx.save_for_backward(h2, rstd, y, norm_w, lm_w, buf, shift_labels, row_lse, sum_cnt)
+        ctx.dims = (B, S, D, V, ldv)
+        ctx.set_materialize_grads(False)
+        return sum_cnt[2:3], logits
+
+    @staticmethod
+    def backward(ctx, dloss, dlogits_ext):
+        B, S, D, V, ldv = ctx.dims
+        M = B * S
+        need = ctx.needs_input_grad
+        if ctx.has_loss:
+            h2, rstd, y, norm_w, lm_w, buf, labels, row_lse, sum_cnt = ctx.saved_tensors
+        else:
+            h2, rstd, y, norm_w, lm_w = ctx.saved_tensors
+        dl = None
+        if ctx.has_loss and dloss is not None:
+            gs = _c2(dloss.to(torch.float32), 1, 1) if dloss.dtype != torch.float32 else dloss
+            dl = ops.cross_entropy_bwd(buf, labels, row_lse, sum_cnt, V, grad_scale=1.0,
+                                       grad_scale_dev=gs.contiguous())
+        if dlogits_ext is not None:
+            ext = torch.empty((M, ldv), dtype=h2.dtype, device=h2.device)
+            ops.fill_(ext, 0.0)
+            src = dlogits_ext.reshape(M, V)
+            ops.copy2d(src, ext, M, V, src.stride(0), ldv)
+            dl = ext if dl is None else ops.add(dl, ext, out=dl)
+        if dl is None:
+            return None, None, None, None, None
+        dlv = dl[:, :V]
+        dy = ops.linear_dx(dlv, lm_w)
+        dlm = ops.linear_dw(dlv, y) if need[2] else None
+        dh, dnw = ops.rmsnorm_bwd(dy, h2, norm_w, rstd)
+        return dh.view(B, S, D), (dnw if need[1] else None), dlm, None, None
+
+
+# =========================================================================
+# pre-LN transformer encoder layer (HF CLIPEncoderLayer / WhisperEncoderLayer)
+# =========================================================================
+ACT_CODE = {"gelu": 1, "quick_gelu": 2}
+
+
+class EncoderLayerFn(torch.autograd.Function):
+    """x + attn(LN1(x)) ; h + fc2(act(fc1(LN2(h)))).  k_proj bias may be None (Whisper)."""
+
+    @staticmethod
+    def forward(ctx, x, n_heads, eps, act, ln1w, ln1b, wq, bq, wk, bk, wv, bv, wo, bo, ln2w, ln2b,
+                w1, b1, w2, b2):
+        B, T, E = x.shape
+        M, H, hd = B * T, n_heads, E // n_heads
+        x2 = _c2(x, M, E)
+        y1, mean1, rstd1 = ops.layernorm_fwd(x2, ln1w, ln1b, eps)
+        q = ops.linear_fwd(y1, wq, bias=bq)
+        k = ops.linear_fwd(y1, wk, bias=bk)
+        v = ops.linear_fwd(y1, wv, bias=bv)
+        att = torch.empty((M, E), dtype=x.dtype, device=x.device)
+        d = lambda t: TDesc(t, E, T * E)  # noqa: E731
+        probs, _ = attention_fwd(d(q), d(k), d(v), d(att), B, H, T, T, hd, hd ** -0.5)
+        h1 = ops.linear_fwd(att, wo, bias=bo, residual=x2)
+        y2, mean2, rstd2 = ops.layernorm_fwd(h1, ln2w, ln2b, eps)
+        grad_mode = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        if grad_mode:
+            f1 = ops.linear_fwd(y2, w1, bias=b1)
+            a = ops.act_fwd(f1, act)
+        else:  # inference / frozen tower: activation fused into the GEMM epilogue
+            f1 = None
+            a = ops.linear_fwd(y2, w1, bias=b1, act=act)
+        out = ops.linear_fwd(a, w2, bias=b2, residual=h1)
+        if grad_mode:
+            ctx.save_for_backward(x2, mean1, rstd1, y1, q, k, v, probs, att, h1, mean2, rstd2, y2,
+                                  f1, a, ln1w, wq, wk, wv, wo, ln2w, w1, w2)
+            ctx.dims = (B, T, E, H, hd, act, bk is not None)
+        return out.view(B, T, E)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x2, mean1, rstd1, y1, q, k, v, probs, att, h1, mean2, rstd2, y2, f1, a, ln1w, wq, wk, wv,
+         wo, ln2w, w1, w2) = ctx.saved_tensors
+        B, T, E, H, hd, act, has_bk = ctx.dims
+        M = B * T
+        dout2 = _c2(dout, M, E)
+        da = ops.linear_dx(dout2, w2)
+        dw2, db2 = ops.linear_dw(dout2, a), ops.colsum(dout2)
+        df1 = ops.act_bwd(f1, da, act)
+        dy2 = ops.linear_dx(df1, w1)
+        dw1, db1 = ops.linear_dw(df1, y2), ops.colsum(df1)
+        dh1, dln2w, dln2b = ops.layernorm_bwd(dy2, h1, ln2w, mean2, rstd2, dres=dout2)
+        datt = ops.linear_dx(dh1, wo)
+        dwo, dbo = ops.linear_dw(dh1, att), ops.colsum(dh1)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        d = lambda t: TDesc(t, E, T * E)  # noqa: E731
+        attention_bwd(d(datt), d(q), d(k), d(v), probs, None, d(dq), d(dk), d(dv), B, H, T, T, hd,
+                      hd ** -0.5)
+        dy1 = ops.linear_dx(dq, wq)
+        ops.linear_dx(dk, wk, out=dy1, accumulate=True)
+        ops.linear_dx(dv, wv, out=dy1, accumulate=True)
+        dwq, dbq = ops.linear_dw(dq, y1), ops.colsum(dq)
+        dwk, dbk = ops.linear_dw(dk, y1), (ops.colsum(dk) if has_bk else None)
+        dwv, dbv = ops.linear_dw(dv, y1), ops.colsum(dv)
+        dx, dln1w, dln1b = ops.layernorm_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dh1)
+        return (dx.view(B, T, E), None, None, None, dln1w, dln1b, dwq, dbq, dwk, dbk, dwv, dbv, dwo,
+                dbo, dln2w, dln2b, dw1, db1, dw2, db2)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        shp = x.shape
+        x2 = _c2(x, x.numel() // shp[-1], shp[-1])
+        y, mean, rstd = ops.layernorm_fwd(x2, w, b, eps)
+        ctx.save_for_backward(x2, w, mean, rstd)
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, mean, rstd = ctx.saved_tensors
+        dx, dw, db = ops.layernorm_bwd(_c2(dy, x2.shape[0], x2.shape[1]), x2, w, mean, rstd)
+        return dx.view(dy.shape), dw, db, None
+
+
+class RMSNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        shp = x.shape
+        x2 = _c2(x, x.numel() // shp[-1], shp[-1])
+        _, y, rstd = ops.rmsnorm_fwd(x2, w, eps)
+        ctx.save_for_backward(x2, w, rstd)
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, rstd = ctx.saved_tensors
+        dx, dw = ops.rmsnorm_bwd(_c2(dy, x2.shape[0], x2.shape[1]), x2, w, rstd)
+        return dx.view(dy.shape), dw, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b): nn.Linear call sites outside the fused blocks."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        shp = x.shape
+        x2 = _c2(x, x.numel() // shp[-1], shp[-1])
+        if act:
+            pre = ops.linear_fwd(x2, w, bias=b)
+            y = ops.act_fwd(pre, act)
+        else:
+            pre = None
+            y = ops.linear_fwd(x2, w, bias=b)
+        ctx.save_for_backward(x2, w, pre)
+        ctx.act, ctx.has_b = act, b is not None
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, pre = ctx.saved_tensors
+        dy2 = _c2(dy, x2.shape[0], w.shape[0])
+        if ctx.act:
+            dy2 = ops.act_bwd(pre, dy2, ctx.act)
+        need = ctx.needs_input_grad
+        dx = ops.linear_dx(dy2, w).view(*dy.shape[:-1], w.shape[1]) if need[0] else None
+        dw = ops.linear_dw(dy2, x2) if need[1] else None
+        db = ops.colsum(dy2) if (ctx.has_b and need[2]) else None
+        return dx, dw, db, None
+
+
+# =========================================================================
+# nn.MultiheadAttention(add_bias_kv, add_zero_attn, dropout) as SELF attention
+# (video_long_self_attention, modeling.py:906-910,1078); batch-first inside.
+# =========================================================================
+class MHASelfFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n_heads, p, seed, in_w, in_b, bias_k, bias_v, out_w, out_b):
+        B, L, E = x.shape
+        H, hd, Lk = n_heads, E // n_heads, L + 2
+        x2 = _c2(x, B * L, E)
+        q = ops.linear_fwd(x2, in_w[:E], bias=in_b[:E])
+        # K|V rows per sample: [L projected rows, bias_k|bias_v row, zero row]
+        kv = torch.empty((B, Lk, 2 * E), dtype=x.dtype, device=x.device)
+        ops.fill_(kv, 0.0)
+        ops.gemm_raw(x2, in_w, kv, L, 2 * E, E, E, E, 2 * E, bias=in_b[E:], bias_mode=1, nb1=B,
+                     sA=(L * E, 0), sC=(Lk * 2 * E, 0), b_off=E * E)
+        ops.copy2d(bias_k, kv, 1, E, E, 2 * E, batch=B, s_src=0, s_dst=Lk * 2 * E, dst_off=L * 2 * E)
+        ops.copy2d(bias_v, kv, 1, E, E, 2 * E, batch=B, s_src=0, s_dst=Lk * 2 * E,
+                   dst_off=L * 2 * E + E)
+        att = torch.empty((B * L, E), dtype=x.dtype, device=x.device)
+        kd, vd = TDesc(kv, 2 * E, Lk * 2 * E, 0), TDesc(kv, 2 * E, Lk * 2 * E, E)
+        probs, pd = attention_fwd(TDesc(q, E, L * E), kd, vd, TDesc(att, E, L * E), B, H, L, Lk, hd,
+                                  math.sqrt(1.0 / hd), p=p, seed=seed)
+        out = ops.linear_fwd(att, out_w, bias=out_b)
+        ctx.save_for_backward(x2, q, kv, probs, pd, att, in_w, out_w)
+        ctx.dims = (B, L, E, H, hd, p, seed)
+        return out.view(B, L, E)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, q, kv, probs, pd, att, in_w, out_w = ctx.saved_tensors
+        B, L, E, H, hd, p, seed = ctx.dims
+        Lk = L + 2
+        need = ctx.needs_input_grad
+        dout2 = _c2(dout, B * L, E)
+        datt = ops.linear_dx(dout2, out_w)
+        dwo, dbo = ops.linear_dw(dout2, att), ops.colsum(dout2)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        kd, vd = TDesc(kv, 2 * E, Lk * 2 * E, 0), TDesc(kv, 2 * E, Lk * 2 * E, E)
+        dkd, dvd = TDesc(dkv, 2 * E, Lk * 2 * E, 0), TDesc(dkv, 2 * E, Lk * 2 * E, E)
+        attention_bwd(TDesc(datt, E, L * E), TDesc(q, E, L * E), kd, vd, probs, pd,
+                      TDesc(dq, E, L * E), dkd, dvd, B, H, L, Lk, hd, math.sqrt(1.0 / hd), p=p,
+                      seed=seed)
+        # bias_k / bias_v grads: sum over batch of row L
+        rows = dkv.view(B * Lk, 2 * E)
+        brow = torch.empty((B, 2 * E), dtype=x2.dtype, device=x2.device)
+        ops.copy2d(rows, brow, 1, 2 * E, 2 * E, 2 * E, batch=B, s_src=Lk * 2 * E, s_dst=2 * E,
+                   src_off=L * 2 * E)
+        bsum = ops.colsum(brow)
+        dbk, dbv = bsum[:E].view(1, 1, E), bsum[E:].view(1, 1, E)
+        # compact the projected rows [B, L, 2E] (drop the 2 extra rows per sample)
+        dkvc = torch.empty((B * L, 2 * E), dtype=x2.dtype, device=x2.device)
+        ops.copy2d(rows, dkvc, L, 2 * E, 2 * E, 2 * E, batch=B, s_src=Lk * 2 * E, s_dst=L * 2 * E)
+        din_w = torch.empty_like(in_w)
+        din_b = torch.empty((3 * E,), dtype=x2.dtype, device=x2.device)
+        ops.linear_dw(dq, x2, out=din_w[:E])
+        ops.linear_dw(dkvc, x2, out=din_w[E:])
+        ops.colsum(dq, out=din_b[:E])
+        ops.colsum(dkvc, out=din_b[E:])
+        dx = None
+        if need[0]:
+            dx = ops.linear_dx(dq, in_w[:E])
+            ops.linear_dx(dkvc, in_w[E:], out=dx, accumulate=True)
+            dx = dx.view(B, L, E)
+        return dx, None, None, None, din_w, din_b, dbk, dbv, dwo, dbo
+
+
+# =========================================================================
+# Multimodal prefix: Conv1d -> Linear -> alignment attention -> splice
+# (modeling.py:965-1048) as ONE block, K/V of the embedding table projected once per
+# step and shared by the whole batch, dE accumulated in place.
+# =========================================================================
+MODALITIES = ("image", "audio", "video")  # final prefix order after BOS
+N_ALIGN_PARAMS = 10  # conv_w, conv_b, lin_w, lin_b, in_w, in_b, bias_k, bias_v, out_w, out_b
+
+
+def _align_fwd(feats, E, prm, heads, kw, stride, p, seed):
+    conv_w, conv_b, lin_w, lin_b, in_w, in_b, bias_k, bias_v, out_w, out_b = prm
+    B, T, C = feats.shape
+    V, D = E.shape
+    H, hd = heads, D // heads
+    f2 = _c2(feats, B * T, C)
+    cols, Lout = ops.im2col1d(f2, B, C, T, kw, stride, 0, T * C, 1, C)
+    K = C * kw
+    cw = conv_w.view(conv_w.shape[0], K)
+    pj = torch.empty((B * Lout, cw.shape[0]), dtype=feats.dtype, device=feats.device)
+    ops.gemm_raw(cols, cw, pj, B * Lout, cw.shape[0], K, cols.stride(0), K, cw.shape[0], bias=conv_b,
+                 bias_mode=1)
+    t = ops.linear_fwd(pj, lin_w, bias=lin_b)
+    Lq = B * Lout
+    q = ops.linear_fwd(t, in_w[:D], bias=in_b[:D])
+    Lk = V + 2
+    kv = torch.empty((Lk, 2 * D), dtype=feats.dtype, device=feats.device)
+    ops.gemm_raw(E, in_w, kv, V, 2 * D, D, D, D, 2 * D, bias=in_b[D:], bias_mode=1, b_off=D * D)
+    ops.copy2d(bias_k, kv, 1, D, D, 2 * D, dst_off=V * 2 * D)
+    ops.copy2d(bias_v, kv, 1, D, D, 2 * D, dst_off=V * 2 * D + D)
+    ops.fill_(kv[V + 1], 0.0)
+    o = torch.empty((Lq, D), dtype=feats.dtype, device=feats.device)
+    kd, vd = TDesc(kv, 2 * D, 0, 0), TDesc(kv, 2 * D, 0, D)
+    probs, pd = attention_fwd(TDesc(q, D, 0), kd, vd, TDesc(o, D, 0), 1, H, Lq, Lk, hd,
+                              math.sqrt(1.0 / hd), p=p, seed=seed)
+    aligned = ops.linear_fwd(o, out_w, bias=out_b)  # rows are (b, j): [B, Lout, D]
+    saved = (f2, cols, pj, t, q, kv, probs, pd, o)
+    return aligned, Lout, saved
+
+
+def _align_bwd(da, E, dE, dE_init, prm, saved, dims, need_feats):
+    """da [B*Lout, D]. Accumulates the table gradient into dE (initialised iff dE_init)."""
+    conv_w, conv_b, lin_w, lin_b, in_w, in_b, bias_k, bias_v, out_w, out_b = prm
+    f2, cols, pj, t, q, kv, probs, pd, o = saved
+    B, T, C, Lout, H, kw, stride, p, seed = dims
+    V, D = E.shape
+    hd, Lq, Lk = D // H, B * Lout, V + 2
+    g = {}
+    g["out_w"], g["out_b"] = ops.linear_dw(da, o), ops.colsum(da)
+    do = ops.linear_dx(da, out_w)
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    kd, vd = TDesc(kv, 2 * D, 0, 0), TDesc(kv, 2 * D, 0, D)
+    attention_bwd(TDesc(do, D, 0), TDesc(q, D, 0), kd, vd, probs, pd, TDesc(dq, D, 0),
+                  TDesc(dkv, 2 * D, 0, 0), TDesc(dkv, 2 * D, 0, D), 1, H, Lq, Lk, hd,
+                  math.sqrt(1.0 / hd), p=p, seed=seed)
+    brow = torch.empty((1, 2 * D), dtype=da.dtype, device=da.device)
+    ops.copy2d(dkv, brow, 1, 2 * D, 2 * D, 2 * D, src_off=V * 2 * D)
+    g["bias_k"], g["bias_v"] = brow[0, :D].reshape(1, 1, D), brow[0, D:].reshape(1, 1, D)
+    dkvt = dkv[:V]
+    # table gradient: dE (+)= dKV W_kv
+    ops.linear_dx(dkvt, in_w[D:], out=dE, accumulate=not dE_init)
+    din_w = torch.empty_like(in_w)
+    din_b = torch.empty((3 * D,), dtype=da.dtype, device=da.device)
+    ops.linear_dw(dq, t, out=din_w[:D])
+    ops.linear_dw(dkvt, E, out=din_w[D:])
+    ops.colsum(dq, out=din_b[:D])
+    ops.colsum(dkvt, out=din_b[D:])
+    g["in_w"], g["in_b"] = din_w, din_b
+    dt = ops.linear_dx(dq, in_w[:D])
+    g["lin_w"], g["lin_b"] = ops.linear_dw(dt, pj), ops.colsum(dt)
+    dpj = ops.linear_dx(dt, lin_w)
+    K = C * kw
+    cw = conv_w.view(conv_w.shape[0], K)
+    dcw = torch.empty_like(cw)
+    ops.gemm_raw(dpj, cols, dcw, cw.shape[0], K, Lq, dpj.stride(0), cols.stride(0), K, a_red=True,
+                 b_red=True)
+    g["conv_w"], g["conv_b"] = dcw.view_as(conv_w), ops.colsum(dpj)
+    dfeats = None
+    if need_feats:
+        dcols = torch.empty((Lq, cols.shape[1]), dtype=da.dtype, device=da.device)
+        ops.gemm_raw(dpj, cw, dcols, Lq, K, cw.shape[0], dpj.stride(0), K, cols.shape[1], b_red=True)
+        dfeats = ops.col2im1d(dcols, B, C, T, kw, stride, 0, Lout, T * C, 1, C, (B, T, C))
+    return g, dfeats
+
+
+class PrefixAssembleFn(torch.autograd.Function):
+    """inputs_embeds = [BOS][<image> a_img </image>][<audio> a_aud </audio>][<video> a_vid
+    </video>][text 1:]  (modeling.py:977-1034; order verified in SURVEY A8).
+
+    meta: dict(ids_full [B,S] int64 with -1 at feature slots, slots {name: (start, Lq)},
+               heads, geom {name: (kernel, stride)}, p, seeds {name: seed}, padding_idx)."""
+
+    @staticmethod
+    def forward(ctx, E, meta, image_f, audio_f, video_f, *params):
+        feats = dict(image=image_f, audio=audio_f, video=video_f)
+        ids_full = meta["ids_full"]
+        B, S = ids_full.shape
+        V, D = E.shape
+        out = torch.empty((B, S, D), dtype=E.dtype, device=E.device)
+        ops.embedding_fwd(E, ids_full.view(-1), out=out.view(B * S, D))
+        saved, dims = {}, {}
+        for i, name in enumerate(MODALITIES):
+            f = feats[name]
+            if f is None:
+                continue
+            prm = params[i * N_ALIGN_PARAMS:(i + 1) * N_ALIGN_PARAMS]
+            kw, stride = meta["geom"][name]
+            aligned, Lout, sv = _align_fwd(f, E, prm, meta["heads"], kw, stride, meta["p"],
+                                           meta["seeds"][name])
+            start, Lq = meta["slots"][name]
+            assert Lq == Lout, (name, Lq, Lout)
+            ops.copy2d(aligned, out, Lout, D, D, D, batch=B, s_src=Lout * D, s_dst=S * D,
+                       dst_off=start * D)
+            saved[name] = sv
+            dims[name] = (f.shape[0], f.shape[1], f.shape[2], Lout, meta["heads"], kw, stride,
+                          meta["p"], meta["seeds"][name])
+        ctx.meta, ctx.dims_, ctx.saved_ = meta, dims, saved
+        ctx.params = params
+        ctx.E = E
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        meta, E, params = ctx.meta, ctx.E, ctx.params
+        ids_full = meta["ids_full"]
+        B, S = ids_full.shape
+        V, D = E.shape
+        need = ctx.needs_input_grad
+        dout2 = _c2(dout, B * S, D)
+        dE = torch.empty_like(E)
+        dE_init = True
+        grads = [None] * (len(MODALITIES) * N_ALIGN_PARAMS)
+        dfeats = dict(image=None, audio=None, video=None)
+        order = ("conv_w", "conv_b", "lin_w", "lin_b", "in_w", "in_b", "bias_k", "bias_v", "out_w",
+                 "out_b")
+        for i, name in enumerate(MODALITIES):
+            if name not in ctx.saved_:
+                continue
+            prm = params[i * N_ALIGN_PARAMS:(i + 1) * N_ALIGN_PARAMS]
+            start, Lq = meta["slots"][name]
+            da = torch.empty((B * Lq, D), dtype=dout.dtype, device=dout.device)
+            ops.copy2d(dout2, da, Lq, D, D, D, batch=B, s_src=S * D, s_dst=Lq * D, src_off=start * D)
+            g, df = _align_bwd(da, E, dE, dE_init, prm, ctx.saved_[name], ctx.dims_[name],
+                               need[2 + i])
+            dE_init = False
+            for j, key in enumerate(order):
+                grads[i * N_ALIGN_PARAMS + j] = g[key]
+            dfeats[name] = df
+        if dE_init:
+            ops.fill_(dE, 0.0)
+        ops.embedding_bwd_(dE, dout2, ids_full.view(-1), padding_idx=meta.get("padding_idx", -1))
+        ctx.saved_ = None
+        return (dE, None, dfeats["image"], dfeats["audio"], dfeats["video"], *grads)
+
+
+# =========================================================================
+# encoder stems / heads (HF CLIPVisionEmbeddings, visual_projection, Whisper conv stem)
+# =========================================================================
+class ClipEmbedFn(torch.autograd.Function):
+    """[CLS + pos[0] ; patch_embed(x) + pos[1:]] — Conv2d(k=P, s=P, no bias) as patchify + GEMM
+    written straight into rows 1.. of the [B, T, E] buffer with the position rows as the
+    GEMM residual."""
+
+    @staticmethod
+    def forward(ctx, x, patch_w, cls, pos, P):
+        B, C, Hh, Ww = x.shape
+        E = patch_w.shape[0]
+        G = (Hh // P) * (Ww // P)
+        T = G + 1
+        K = C * P * P
+        cols = ops.patchify(x, P)
+        ldk = cols.shape[1]
+        wp = torch.empty((E, ldk), dtype=x.dtype, device=x.device)
+        if ldk != K:
+            ops.fill_(wp, 0.0)
+        ops.copy2d(patch_w.view(E, K), wp, E, K, K, ldk)
+        out = torch.empty((B, T, E), dtype=x.dtype, device=x.device)
+        ops.gemm_raw(cols, wp, out, G, E, ldk, ldk, ldk, E, R=pos, ldr=E, nb1=B, sA=(G * ldk, 0),
+                     sC=(T * E, 0), sR=(0, 0), c_off=E, r_off=E)
+        clsrow = ops.add(cls.view(-1), pos[0].contiguous().view(-1))
+        ops.copy2d(clsrow, out, 1, E, E, E, batch=B, s_src=0, s_dst=T * E)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(cols, wp)
+            ctx.dims = (B, C, Hh, Ww, P, E, G, T, K, ldk)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cols, wp = ctx.saved_tensors
+        B, C, Hh, Ww, P, E, G, T, K, ldk = ctx.dims
+        need = ctx.needs_input_grad
+        d2 = _c2(dout, B, T * E)
+        dpos = ops.colsum(d2).view(T, E) if need[3] else None
+        dcls = None
+        if need[2]:
+            first = torch.empty((B, E), dtype=dout.dtype, device=dout.device)
+            ops.copy2d(d2, first, 1, E, E, E, batch=B, s_src=T * E, s_dst=E)
+            dcls = ops.colsum(first)
+        dy = torch.empty((B * G, E), dtype=dout.dtype, device=dout.device)
+        ops.copy2d(d2, dy, G, E, E, E, batch=B, s_src=T * E, s_dst=G * E, src_off=E)
+        dw = None
+        if need[1]:
+            dwp = ops.linear_dw(dy, cols)            # [E, ldk]
+            dw = torch.empty((E, K), dtype=dout.dtype, device=dout.device)
+            ops.copy2d(dwp, dw, E, K, ldk, K)
+            dw = dw.view(E, C, P, P)
+        dx = None
+        if need[0]:
+            dcols = ops.linear_dx(dy, wp)            # [B*G, ldk]
+            dx = ops.unpatchify(dcols, B, C, Hh, Ww, P)
+        return dx, dw, dcls, dpos, None
+
+
+class DropClsProjectFn(torch.autograd.Function):
+    """visual_projection(h)[:, 1:, :] without computing the CLS row (bias-free Linear)."""
+
+    @staticmethod
+    def forward(ctx, h, w):
+        B, T, E = h.shape
+        Pd = w.shape[0]
+        hc = _c2(h, B * T, E)
+        out = torch.empty((B, T - 1, Pd), dtype=h.dtype, device=h.device)
+        ops.gemm_raw(hc, w, out, T - 1, Pd, E, E, E, Pd, nb1=B, sA=(T * E, 0), sC=((T - 1) * Pd, 0),
+                     a_off=E)
+        ctx.save_for_backward(hc, w)
+        ctx.dims = (B, T, E, Pd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        hc, w = ctx.saved_tensors
+        B, T, E, Pd = ctx.dims
+        need = ctx.needs_input_grad
+        dy = _c2(dout, B * (T - 1), Pd)
+        dh = dw = None
+        if need[0]:
+            dh = torch.empty((B, T, E), dtype=dout.dtype, device=dout.device)
+            zero = torch.empty((E,), dtype=dout.dtype, device=dout.device)
+            ops.fill_(zero, 0.0)
+            ops.copy2d(zero, dh, 1, E, E, E, batch=B, s_src=0, s_dst=T * E)
+            ops.gemm_raw(dy, w, dh, T - 1, E, Pd, Pd, E, E, b_red=True, nb1=B,
+                         sA=((T - 1) * Pd, 0), sC=(T * E, 0), c_off=E)
+        if need[1]:
+            hs = torch.empty((B * (T - 1), E), dtype=dout.dtype, device=dout.device)
+            ops.copy2d(hc, hs, T - 1, E, E, E, batch=B, s_src=T * E, s_dst=(T - 1) * E, src_off=E)
+            dw = ops.linear_dw(dy, hs)
+        return dh, dw
+
+
+class WhisperStemFn(torch.autograd.Function):
+    """gelu(conv2(gelu(conv1(mel)))) + embed_positions, channels-last output [B, T2, d]:
+    Conv1d(k3,p1) and Conv1d(k3,s2,p1) as window-gather + MFMA GEMM with fused bias/GELU."""
+
+    @staticmethod
+    def forward(ctx, mel, w1, b1, w2, b2, pos):
+        B, Cm, Tm = mel.shape
+        d = w1.shape[0]
+        grad_mode = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        mel = mel.contiguous()
+        cols1, L1 = ops.im2col1d(mel, B, Cm, Tm, 3, 1, 1, Cm * Tm, Tm, 1)
+        w1v = w1.view(d, Cm * 3)
+        if grad_mode:
+            pre1 = ops.linear_fwd(cols1, w1v, bias=b1)
+            h1 = ops.act_fwd(pre1, 1)
+        else:
+            pre1 = None
+            h1 = ops.linear_fwd(cols1, w1v, bias=b1, act=1)
+        cols2, T2 = ops.im2col1d(h1, B, d, L1, 3, 2, 1, L1 * d, 1, d)
+        w2v = w2.view(d, d * 3)
+        ld2 = cols2.shape[1]
+        out = torch.empty((B, T2, d), dtype=mel.dtype, device=mel.device)
+        if grad_mode:
+            pre2 = ops.linear_fwd(cols2, w2v, bias=b2)
+            a2 = ops.act_fwd(pre2, 1)
+            ops.add(a2, pos.contiguous().view(-1), out=out, period=T2 * d)
+        else:
+            pre2 = None
+            ops.gemm_raw(cols2, w2v, out, T2, d, d * 3, ld2, d * 3, d, bias=b2, bias_mode=1, act=1,
+                         R=pos, ldr=d, nb1=B, sA=(T2 * ld2, 0), sC=(T2 * d, 0), sR=(0, 0))
+        if grad_mode:
+            ctx.save_for_backward(cols1, pre1, cols2, pre2, w1v, w2v)
+            ctx.dims = (B, Cm, Tm, d, L1, T2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cols1, pre1, cols2, pre2, w1v, w2v = ctx.saved_tensors
+        B, Cm, Tm, d, L1, T2 = ctx.dims
+        need = ctx.needs_input_grad
+        d2 = _c2(dout, B * T2, d)
+        dpos = ops.colsum(_c2(dout, B, T2 * d)).view(T2, d) if need[5] else None
+        dpre2 = ops.act_bwd(pre2, d2, 1)
+        dw2 = ops.linear_dw(dpre2, cols2)[:, : d * 3].contiguous().view(d, d, 3) if need[3] else None
+        db2 = ops.colsum(dpre2) if need[4] else None
+        dcols2 = ops.linear_dx(dpre2, w2v)
+        dh1 = ops.col2im1d(dcols2, B, d, L1, 3, 2, 1, T2, L1 * d, 1, d, (B * L1, d))
+        dpre1 = ops.act_bwd(pre1, dh1, 1)
+        dw1 = ops.linear_dw(dpre1, cols1)[:, : Cm * 3].contiguous().view(d, Cm, 3) if need[1] else None
+        db1 = ops.colsum(dpre1) if need[2] else None
+        dmel = None
+        if need[0]:
+            dcols1 = ops.linear_dx(dpre1, w1v)
+            dmel = ops.col2im1d(dcols1, B, Cm, Tm, 3, 1, 1, L1, Cm * Tm, Tm, 1, (B, Cm, Tm))
+        return dmel, dw1, db1, dw2, db2, dpos
+
+
+class AddBroadcastFn(torch.autograd.Function):
+    """x[B, L, h] + pe[L, h]  (add_positional_encoding, modeling.py:1108-1118)."""
+
+    @staticmethod
+    def forward(ctx, x, pe):
+        B = x.shape[0]
+        xc = _c2(x, B, x.numel() // B)
+        out = ops.add(xc, pe.contiguous().view(-1), period=pe.numel())
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout, None

@@ -1,0 +1,591 @@
+"""Drop-in mirror of the reference's `modeling.py` surface on the MI355X-native engine.
+
+Same class names, constructor kwargs, attribute names and state-dict keys as
+/root/reference/modeling.py (MM_LLMs_Config :807-861, MM_LLMs :863-1093, the vendored
+LLaMA classes :44-659), so `from modeling import MM_LLMs, MM_LLMs_Config` in
+run_clm_llms.py:95 / llm_trainer.py:114 keeps working (a `modeling.py` shim at the repo root
+re-exports this module).  Every arithmetic op of forward and backward runs in the
+hand-written gfx950 kernels of csrc/ through macaw_llm_amd.engine; there is no eager
+fallback — calling the model on CPU tensors raises MacawHipError.
+
+The CLIP / Whisper towers are instantiated from the installed `transformers` classes purely
+as PARAMETER CONTAINERS (identical module tree => identical checkpoint keys, including the
+never-used text tower / decoder); their HF `forward` is never called.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import CrossEntropyLoss
+from transformers import (CLIPConfig, CLIPModel, LlamaConfig, PretrainedConfig, PreTrainedModel,
+                          WhisperConfig, WhisperModel)
+from transformers.modeling_outputs import BaseModelOutputWithPast, CausalLMOutputWithPast
+
+from . import engine as eng
+from . import ops
+from .lib import MacawHipError
+
+
+def _dev_check(t: torch.Tensor):
+    if not t.is_cuda:
+        raise MacawHipError("macaw_llm_amd runs on the HIP device only (model and inputs must be on "
+                            "'cuda'); there is no CPU path")
+
+
+# ---------------------------------------------------------------- LLaMA -----
+class LlamaRotaryEmbedding(nn.Module):
+    """modeling.py:94-123.  Tables are built once in fp32 and cast to the activation dtype."""
+
+    def __init__(self, dim, max_position_embeddings=2048, base=10000, device=None):
+        super().__init__()
+        inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float().to(device) / dim))
+        self.register_buffer("inv_freq", inv_freq)
+        self.dim, self.base = dim, base
+        self.max_seq_len_cached = max_position_embeddings
+        self._tables = {}
+
+    def tables(self, seq_len, dtype, device):
+        if seq_len > self.max_seq_len_cached:
+            self.max_seq_len_cached = seq_len
+            self._tables = {}
+        key = (dtype, str(device))
+        if key not in self._tables:
+            inv = 1.0 / (self.base ** (torch.arange(0, self.dim, 2).float() / self.dim))
+            t = torch.arange(self.max_seq_len_cached, dtype=inv.dtype)
+            emb = torch.cat((torch.einsum("i,j->ij", t, inv),) * 2, dim=-1)
+            cos, sin = emb.cos().to(device), emb.sin().to(device)  # init-time only
+            self._tables[key] = (ops.cast(cos, dtype), ops.cast(sin, dtype))
+        return self._tables[key]
+
+
+class LlamaRMSNorm(nn.Module):
+    def __init__(self, hidden_size, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, hidden_states):
+        _dev_check(hidden_states)
+        return eng.RMSNormFn.apply(hidden_states, self.weight, self.variance_epsilon)
+
+
+class LlamaMLP(nn.Module):
+    def __init__(self, hidden_size: int, intermediate_size: int, hidden_act: str):
+        super().__init__()
+        if hidden_act != "silu":
+            raise ValueError("LlamaMLP: only hidden_act='silu' is implemented")
+        self.gate_proj = nn.Linear(hidden_size, intermediate_size, bias=False)
+        self.down_proj = nn.Linear(intermediate_size, hidden_size, bias=False)
+        self.up_proj = nn.Linear(hidden_size, intermediate_size, bias=False)
+
+
+class LlamaAttention(nn.Module):
+    def __init__(self, config: LlamaConfig):
+        super().__init__()
+        self.config = config
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self.max_position_embeddings = config.max_position_embeddings
+        if (self.head_dim * self.num_heads) != self.hidden_size:
+            raise ValueError(
+                f"hidden_size must be divisible by num_heads (got `hidden_size`: {self.hidden_size}"
+                f" and `num_heads`: {self.num_heads}).")
+        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=False)
+        self.k_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=False)
+        self.v_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=False)
+        self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=False)
+        self.rotary_emb = LlamaRotaryEmbedding(self.head_dim,
+                                               max_position_embeddings=self.max_position_embeddings)
+
+
+class LlamaDecoderLayer(nn.Module):
+    def __init__(self, config: LlamaConfig):
+        super().__init__()
+        self.hidden_size = config.hidden_size
+        self.self_attn = LlamaAttention(config=config)
+        self.mlp = LlamaMLP(hidden_size=self.hidden_size, intermediate_size=config.intermediate_size,
+                            hidden_act=config.hidden_act)
+        self.input_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, hidden_states, kmask=None, pos=None, past_key_value=None, use_cache=False):
+        """hidden_states [B,S,D]; kmask int32 [B,S] (0 = padding) or None; pos int32 [B*S]."""
+        if past_key_value is not None or use_cache:
+            raise NotImplementedError("KV-cache decode goes through LlamaForCausalLM.generate")
+        a, m = self.self_attn, self.mlp
+        cos, sin = a.rotary_emb.tables(hidden_states.shape[1], hidden_states.dtype,
+                                       hidden_states.device)
+        out = eng.LlamaLayerFn.apply(
+            hidden_states, kmask, pos, cos, sin, a.num_heads, self.input_layernorm.variance_epsilon,
+            a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.o_proj.weight, m.gate_proj.weight,
+            m.up_proj.weight, m.down_proj.weight, self.input_layernorm.weight,
+            self.post_attention_layernorm.weight)
+        return (out,)
+
+
+class LlamaPreTrainedModel(PreTrainedModel):
+    config_class = LlamaConfig
+    base_model_prefix = "model"
+    supports_gradient_checkpointing = True
+    _no_split_modules = ["LlamaDecoderLayer"]
+
+    def _init_weights(self, module):
+        std = self.config.initializer_range
+        if isinstance(module, nn.Linear):
+            module.weight.data.normal_(mean=0.0, std=std)
+            if module.bias is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, nn.Embedding):
+            module.weight.data.normal_(mean=0.0, std=std)
+            if module.padding_idx is not None:
+                module.weight.data[module.padding_idx].zero_()
+
+    def _set_gradient_checkpointing(self, module, value=False):
+        if isinstance(module, LlamaModel):
+            module.gradient_checkpointing = value
+
+
+class LlamaModel(LlamaPreTrainedModel):
+    def __init__(self, config: LlamaConfig):
+        super().__init__(config)
+        self.padding_idx = config.pad_token_id
+        self.vocab_size = config.vocab_size
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, self.padding_idx)
+        self.layers = nn.ModuleList([LlamaDecoderLayer(config) for _ in range(config.num_hidden_layers)])
+        self.norm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.gradient_checkpointing = False
+        self._pos_cache = {}
+        self.post_init()
+
+    def get_input_embeddings(self):
+        return self.embed_tokens
+
+    def set_input_embeddings(self, value):
+        self.embed_tokens = value
+
+    def _positions(self, B, S, device):
+        key = (B, S, str(device))
+        if key not in self._pos_cache:
+            self._pos_cache = {key: torch.arange(S, dtype=torch.int32, device=device).repeat(B)}
+        return self._pos_cache[key]
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
+                inputs_embeds=None, use_cache=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None):
+        if input_ids is not None and inputs_embeds is not None:
+            raise ValueError("You cannot specify both decoder_input_ids and decoder_inputs_embeds at the same time")
+        if input_ids is None and inputs_embeds is None:
+            raise ValueError("You have to specify either decoder_input_ids or decoder_inputs_embeds")
+        if output_attentions:
+            raise NotImplementedError("output_attentions is not supported by the fused engine")
+        if past_key_values is not None or use_cache:
+            raise NotImplementedError("KV-cache decode goes through LlamaForCausalLM.generate")
+        if inputs_embeds is None:
+            _dev_check(input_ids)
+            B, S = input_ids.shape
+            inputs_embeds = EmbeddingFn.apply(self.embed_tokens.weight, input_ids.long().reshape(-1),
+                                              self.padding_idx).view(B, S, -1)
+        _dev_check(inputs_embeds)
+        B, S, _ = inputs_embeds.shape
+        dev = inputs_embeds.device
+        if position_ids is None:  # modeling.py:434-439: arange(S) irrespective of padding
+            pos = self._positions(B, S, dev)
+        else:
+            pos = position_ids.to(torch.int32).expand(B, S).reshape(-1).contiguous()
+        kmask = None
+        if attention_mask is not None:
+            if attention_mask.shape != (B, S):
+                raise ValueError(f"Attention mask should be of size {(B, S)}, but is {tuple(attention_mask.shape)}")
+            kmask = attention_mask.to(torch.int32).contiguous()
+        h = inputs_embeds
+        all_h = () if output_hidden_states else None
+        for layer in self.layers:
+            if output_hidden_states:
+                all_h += (h,)
+            h = layer(h, kmask=kmask, pos=pos)[0]
+        # NOTE: the final RMSNorm is fused with lm_head in LlamaForCausalLM; standalone
+        # LlamaModel.forward applies it here.
+        if getattr(self, "_defer_final_norm", False):
+            return h
+        h = self.norm(h)
+        if output_hidden_states:
+            all_h += (h,)
+        return BaseModelOutputWithPast(last_hidden_state=h, past_key_values=None, hidden_states=all_h,
+                                       attentions=None)
+
+
+class EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, ids, padding_idx):
+        out = ops.embedding_fwd(table, ids)
+        ctx.save_for_backward(ids)
+        ctx.shape, ctx.padding_idx = table.shape, padding_idx
+        ctx.dtype = table.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        dt = torch.empty(ctx.shape, dtype=ctx.dtype, device=dout.device)
+        ops.fill_(dt, 0.0)
+        ops.embedding_bwd_(dt, dout.contiguous(), ids,
+                           -1 if ctx.padding_idx is None else ctx.padding_idx)
+        return dt, None, None
+
+
+class LlamaForCausalLM(LlamaPreTrainedModel):
+    def __init__(self, config):
+        super().__init__(config)
+        self.model = LlamaModel(config)
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.post_init()
+
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+    def set_input_embeddings(self, value):
+        self.model.embed_tokens = value
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def set_output_embeddings(self, new_embeddings):
+        self.lm_head = new_embeddings
+
+    def set_decoder(self, decoder):
+        self.model = decoder
+
+    def get_decoder(self):
+        return self.model
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
+                inputs_embeds=None, labels=None, use_cache=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None):
+        self.model._defer_final_norm = True
+        try:
+            h = self.model(input_ids=input_ids, attention_mask=attention_mask,
+                           position_ids=position_ids, past_key_values=past_key_values,
+                           inputs_embeds=inputs_embeds, use_cache=use_cache,
+                           output_attentions=output_attentions)
+        finally:
+            self.model._defer_final_norm = False
+        shift = None
+        if labels is not None:
+            # Shift so that tokens < n predict n (modeling.py:601-603): row (b,s) is scored
+            # against labels[b, s+1]; the last position of every sample is ignored.
+            labels = labels.to(h.device).long()
+            shift = torch.cat([labels[:, 1:], torch.full_like(labels[:, :1], -100)], dim=1)
+            shift = shift.reshape(-1).contiguous()
+        loss, logits = eng.LMHeadLossFn.apply(h, self.model.norm.weight, self.lm_head.weight, shift,
+                                              self.model.norm.variance_epsilon)
+        loss = loss[0] if labels is not None else None
+        if return_dict is False:
+            return ((loss, logits) if loss is not None else (logits,))
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None,
+                                      hidden_states=None, attentions=None)
+
+    @torch.no_grad()
+    def generate(self, inputs_embeds=None, input_ids=None, max_new_tokens=128, eos_token_id=2,
+                 bos_token_id=1, pad_token_id=None, **_):
+        """Greedy decode (the only mode the reference uses, modeling.py:959).  Round-1
+        implementation recomputes the prefix each step (no KV cache yet): same arithmetic as
+        the cached path, token ids identical.  Returns the NEW token ids [B, <=max_new_tokens]."""
+        if inputs_embeds is None:
+            inputs_embeds = EmbeddingFn.apply(self.model.embed_tokens.weight,
+                                              input_ids.long().reshape(-1), None
+                                              ).view(*input_ids.shape, -1)
+        emb = inputs_embeds
+        B = emb.shape[0]
+        pad = pad_token_id if pad_token_id is not None else (eos_token_id or 0)
+        done = torch.zeros(B, dtype=torch.bool, device=emb.device)
+        out = []
+        for _ in range(max_new_tokens):
+            logits = self(inputs_embeds=emb).logits[:, -1, :]
+            nxt = logits.float().argmax(-1)
+            nxt = torch.where(done, torch.full_like(nxt, pad), nxt)
+            out.append(nxt)
+            done = done | (nxt == eos_token_id)
+            if bool(done.all()):
+                break
+            e = ops.embedding_fwd(self.model.embed_tokens.weight, nxt.contiguous())
+            nemb = torch.empty((B, emb.shape[1] + 1, emb.shape[2]), dtype=emb.dtype, device=emb.device)
+            S0, D = emb.shape[1], emb.shape[2]
+            ops.copy2d(emb.contiguous(), nemb, S0, D, D, D, batch=B, s_src=S0 * D, s_dst=(S0 + 1) * D)
+            ops.copy2d(e, nemb, 1, D, D, D, batch=B, s_src=D, s_dst=(S0 + 1) * D, dst_off=S0 * D)
+            emb = nemb
+        return torch.stack(out, dim=1)
+
+
+# ---------------------------------------------------------- multimodal ------
+class MM_LLMs_Config(PretrainedConfig):
+    model_type = "mm_llms"
+    is_composition = True
+
+    def __init__(self, n_frames=6, attention_heads=8, image_conv_kernel=48, image_conv_stride=36,
+                 video_conv_kernel=36, video_conv_stride=30, audio_conv_kernel=240,
+                 audio_conv_stride=220, clip_config=None, whisper_config=None, llm_config=None,
+                 **kwargs):
+        self.image_config = clip_config
+        self.audio_config = whisper_config
+        self.llm_config = llm_config
+        self.n_frames = n_frames
+        self.attention_heads = attention_heads
+        self.image_conv_kernel = image_conv_kernel
+        self.image_conv_stride = image_conv_stride
+        self.video_conv_kernel = video_conv_kernel
+        self.video_conv_stride = video_conv_stride
+        self.audio_conv_kernel = audio_conv_kernel
+        self.audio_conv_stride = audio_conv_stride
+        self.hidden_size = max(llm_config.hidden_size, clip_config.projection_dim,
+                               whisper_config.d_model, clip_config.projection_dim)
+        super().__init__(**kwargs)
+
+    def to_dict(self):
+        output = copy.deepcopy(self.__dict__)
+        output["image_config"] = self.image_config.to_dict()
+        output["audio_config"] = self.audio_config.to_dict()
+        output["llm_config"] = self.llm_config.to_dict()
+        for k in ("n_frames", "attention_heads", "image_conv_kernel", "image_conv_stride",
+                  "video_conv_kernel", "video_conv_stride", "audio_conv_kernel", "audio_conv_stride",
+                  "hidden_size"):
+            output[k] = getattr(self, k)
+        output["model_type"] = self.__class__.model_type
+        return output
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, **kwargs):
+        config_dict, kwargs = cls.get_config_dict(pretrained_model_name_or_path, **kwargs)
+        clip_config = CLIPConfig.from_dict(config_dict["image_config"])
+        whisper_config = WhisperConfig.from_dict(config_dict["audio_config"])
+        llm_config = LlamaConfig.from_dict(config_dict["llm_config"])
+        return cls(clip_config=clip_config, whisper_config=whisper_config, llm_config=llm_config,
+                   **kwargs)
+
+
+def _mha_params(m: nn.MultiheadAttention):
+    return (m.in_proj_weight, m.in_proj_bias, m.bias_k, m.bias_v, m.out_proj.weight, m.out_proj.bias)
+
+
+class MM_LLMs(PreTrainedModel):
+    config_class = MM_LLMs_Config
+    supports_gradient_checkpointing = True
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.config = config
+        self.temporal_position_embeddings = nn.Embedding(config.n_frames, config.image_config.projection_dim)
+        self.image_encoder = CLIPModel(config.image_config)
+        self.video_encoder = CLIPModel(config.image_config)
+        self.audio_encoder = WhisperModel(config.audio_config)
+        self.llm = LlamaForCausalLM(config.llm_config)
+        attn_dropout, kv, za = 0.1, True, True
+        pd, D = config.image_config.projection_dim, config.llm_config.hidden_size
+        mk = lambda e, h: nn.MultiheadAttention(e, h, dropout=attn_dropout, add_bias_kv=kv,  # noqa: E731
+                                                add_zero_attn=za)
+        self.temporal_self_attention = mk(pd, config.attention_heads)
+        self.video_align_attention = mk(D, config.attention_heads * 2)
+        self.audio_align_attention = mk(D, config.attention_heads * 2)
+        self.image_align_attention = mk(D, config.attention_heads * 2)
+        self.video_long_self_attention = mk(pd, config.attention_heads)
+        self.transform_video_to_hidden = nn.Linear(pd, D)
+        self.transform_audio_to_hidden = nn.Linear(config.audio_config.d_model, D)
+        self.transform_image_to_hidden = nn.Linear(pd, D)
+        self.project_image = nn.Conv1d(pd, pd, kernel_size=config.image_conv_kernel,
+                                       stride=config.image_conv_stride)
+        self.project_video = nn.Conv1d(pd, pd, kernel_size=config.video_conv_kernel,
+                                       stride=config.video_conv_stride)
+        self.project_audio = nn.Conv1d(config.audio_config.d_model, config.audio_config.d_model,
+                                       kernel_size=config.audio_conv_kernel,
+                                       stride=config.audio_conv_stride)
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self.layer_norm = nn.LayerNorm(pd)
+        self.softmax = nn.Softmax(dim=-1)
+        self.relu = nn.ReLU()
+        self.gelu = nn.GELU()
+        self.elu = nn.ELU()
+        self.sigmoid = nn.Sigmoid()
+        self.loss_fct = CrossEntropyLoss()
+        self._pe_cache = {}
+        self._step = 0
+        self.dropout_seed = 0x5EED
+        self.post_init()
+
+    # ------------------------------------------------------------ forward ---
+    def forward(self, inputs=None):
+        text_embeddings, attention_mask, labels = self.prepare_inputs_for_generation(inputs)
+        if "inference" in inputs and inputs["inference"] is True:
+            return self.llm.generate(inputs_embeds=text_embeddings, max_new_tokens=128,
+                                     eos_token_id=2, bos_token_id=1, pad_token_id=32006)
+        return self.llm(inputs_embeds=text_embeddings, attention_mask=attention_mask, labels=labels)
+
+    def prepare_inputs_for_generation(self, inputs):
+        """modeling.py:965-1048 — same outputs (inputs_embeds, attention_mask, labels)."""
+        cfg = self.config
+        image_f = self.encode_image(inputs["images"]) if inputs.get("images") is not None else None
+        audio_f = self.encode_audio(inputs["audios"]) if inputs.get("audios") is not None else None
+        video_f = self.encode_video_long(inputs["videos"]) if inputs.get("videos") is not None else None
+        E = self.llm.model.embed_tokens.weight
+        ids = inputs["input_ids"]
+        _dev_check(ids)
+        ids = ids.long()
+        B, L = ids.shape
+        feats = dict(image=image_f, audio=audio_f, video=video_f)
+        geom = dict(image=(cfg.image_conv_kernel, cfg.image_conv_stride),
+                    audio=(cfg.audio_conv_kernel, cfg.audio_conv_stride),
+                    video=(cfg.video_conv_kernel, cfg.video_conv_stride))
+        # integer plumbing: id map of the spliced sequence, -1 where modal features go
+        cols = [ids[:, :1]]
+        slots, pos, ignore = {}, 1, 0
+        for name in eng.MODALITIES:
+            f = feats[name]
+            if f is None:
+                continue
+            kw, st = geom[name]
+            Lq = (f.shape[1] - kw) // st + 1
+            cols += [inputs[f"{name}_starts"].long().view(B, 1),
+                     torch.full((B, Lq), -1, dtype=torch.long, device=ids.device),
+                     inputs[f"{name}_ends"].long().view(B, 1)]
+            slots[name] = (pos + 1, Lq)
+            pos += Lq + 2
+            ignore += Lq + 2
+        cols.append(ids[:, 1:])
+        ids_full = torch.cat(cols, dim=1).contiguous()
+        self._step += 1
+        p = 0.1 if self.training else 0.0
+        meta = dict(ids_full=ids_full, slots=slots, heads=cfg.attention_heads * 2, geom=geom, p=p,
+                    seeds={n: (self.dropout_seed * 1000003 + self._step * 7 + i) & 0x7FFFFFFFFFFF
+                           for i, n in enumerate(eng.MODALITIES)},
+                    padding_idx=-1 if self.llm.model.padding_idx is None else self.llm.model.padding_idx)
+        params = []
+        for name in eng.MODALITIES:
+            conv = getattr(self, f"project_{name}")
+            lin = getattr(self, f"transform_{name}_to_hidden")
+            params += [conv.weight, conv.bias, lin.weight, lin.bias,
+                       *_mha_params(getattr(self, f"{name}_align_attention"))]
+        text_embeddings = eng.PrefixAssembleFn.apply(E, meta, image_f, audio_f, video_f, *params)
+
+        if "attention_mask" in inputs and inputs["attention_mask"] is not None:
+            am = inputs["attention_mask"]
+            attention_mask = torch.cat([torch.ones((B, ignore), dtype=am.dtype, device=am.device), am], dim=1)
+        else:
+            attention_mask = None
+        if "labels" in inputs and inputs["labels"] is not None:
+            lb = inputs["labels"]
+            labels = torch.cat([torch.full((B, ignore), -100, dtype=lb.dtype, device=lb.device), lb], dim=1)
+        else:
+            labels = None
+        return text_embeddings, attention_mask, labels
+
+    # ----------------------------------------------------------- encoders ---
+    def _param_dtype(self):
+        return self.llm.model.embed_tokens.weight.dtype
+
+    def _clip_tokens(self, clip: CLIPModel, images):
+        """visual_projection(vision_model(x)[0])[:, 1:, :]  (modeling.py:1073,1092)."""
+        _dev_check(images)
+        vm = clip.vision_model
+        vcfg = clip.config.vision_config
+        dtype = vm.embeddings.patch_embedding.weight.dtype
+        x = ops.cast(images.contiguous(), dtype)
+        B = x.shape[0]
+        P, Ed = vcfg.patch_size, vcfg.hidden_size
+        g = vcfg.image_size // P
+        T = g * g + 1
+        if x.shape[-1] != vcfg.image_size or x.shape[-2] != vcfg.image_size:
+            raise ValueError(f"Input image size ({x.shape[-2]}*{x.shape[-1]}) doesn't match model "
+                             f"({vcfg.image_size}*{vcfg.image_size}).")
+        h = eng.ClipEmbedFn.apply(x, vm.embeddings.patch_embedding.weight,
+                                  vm.embeddings.class_embedding,
+                                  vm.embeddings.position_embedding.weight, P)
+        h = eng.LayerNormFn.apply(h, vm.pre_layrnorm.weight, vm.pre_layrnorm.bias, vcfg.layer_norm_eps)
+        act = eng.ACT_CODE[vcfg.hidden_act]
+        for lyr in vm.encoder.layers:
+            a, m = lyr.self_attn, lyr.mlp
+            h = eng.EncoderLayerFn.apply(
+                h, vcfg.num_attention_heads, vcfg.layer_norm_eps, act, lyr.layer_norm1.weight,
+                lyr.layer_norm1.bias, a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias,
+                a.v_proj.weight, a.v_proj.bias, a.out_proj.weight, a.out_proj.bias,
+                lyr.layer_norm2.weight, lyr.layer_norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
+                m.fc2.bias)
+        return eng.DropClsProjectFn.apply(h, clip.visual_projection.weight)
+
+    def encode_image(self, images):
+        return self._clip_tokens(self.image_encoder, images)
+
+    def encode_audio(self, audios):
+        """audio_encoder.encoder(audios)[0]  (modeling.py:1081-1083)."""
+        _dev_check(audios)
+        enc = self.audio_encoder.encoder
+        wcfg = self.audio_encoder.config
+        dtype = enc.conv1.weight.dtype
+        x = ops.cast(audios.contiguous(), dtype)
+        expected = wcfg.max_source_positions * 2
+        if x.shape[-1] != expected:
+            raise ValueError(f"Whisper expects the mel input features to be of length {expected}, "
+                             f"but found {x.shape[-1]}.")
+        h = eng.WhisperStemFn.apply(x, enc.conv1.weight, enc.conv1.bias, enc.conv2.weight,
+                                    enc.conv2.bias, enc.embed_positions.weight)
+        act = eng.ACT_CODE[wcfg.activation_function]
+        for lyr in enc.layers:
+            a = lyr.self_attn
+            h = eng.EncoderLayerFn.apply(
+                h, wcfg.encoder_attention_heads, 1e-5, act, lyr.self_attn_layer_norm.weight,
+                lyr.self_attn_layer_norm.bias, a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, None,
+                a.v_proj.weight, a.v_proj.bias, a.out_proj.weight, a.out_proj.bias,
+                lyr.final_layer_norm.weight, lyr.final_layer_norm.bias, lyr.fc1.weight, lyr.fc1.bias,
+                lyr.fc2.weight, lyr.fc2.bias)
+        return eng.LayerNormFn.apply(h, enc.layer_norm.weight, enc.layer_norm.bias, 1e-5)
+
+    def encode_video_long(self, videos):
+        """modeling.py:1070-1079."""
+        _dev_check(videos)
+        nf = self.config.n_frames
+        frames = videos.reshape(-1, videos.size(-3), videos.size(-2), videos.size(-1))
+        f = self._clip_tokens(self.video_encoder, frames)           # [B*nf, T, pd]
+        Bv = frames.size(0) // nf
+        f = f.reshape(Bv, nf * f.size(1), f.size(2))
+        pe = self._positional_encoding(f.size(1), f.size(2), f.dtype, f.device)
+        f = eng.AddBroadcastFn.apply(f, pe)
+        m = self.video_long_self_attention
+        p = m.dropout if self.training else 0.0
+        seed = (self.dropout_seed * 7919 + self._step * 13 + 5) & 0x7FFFFFFFFFFF
+        return eng.MHASelfFn.apply(f, m.num_heads, p, seed, *_mha_params(m))
+
+    def _positional_encoding(self, L, h, dtype, device):
+        """create_positional_encoding (modeling.py:1095-1106) is input independent: built once
+        per (L, h) instead of by a 590k-iteration Python loop every forward."""
+        key = (L, h, dtype, str(device))
+        if key not in self._pe_cache:
+            i = torch.arange(0, h, 2, dtype=torch.float32)
+            div = torch.exp(-(math.log(10000.0) / h * (2 * i)))
+            posn = torch.arange(L, dtype=torch.float32)[:, None]
+            pe = torch.zeros(L, h)
+            pe[:, 0::2] = torch.sin(posn * div)
+            pe[:, 1::2] = torch.cos(posn * div)
+            self._pe_cache[key] = ops.cast(pe.to(device), dtype)
+        return self._pe_cache[key]
+
+    def encode_video(self, videos):
+        raise NotImplementedError("encode_video is dead code in the reference (modeling.py:969 uses "
+                                  "encode_video_long); not on the hot path")
+
+
+create_positional_encoding = None  # the reference's python-loop helper is not part of the product path
+
+
+def add_positional_encoding(tensor):
+    """modeling.py:1108-1118 on the device path."""
+    N, L, h = tensor.size()
+    i = torch.arange(0, h, 2, dtype=torch.float32)
+    div = torch.exp(-(math.log(10000.0) / h * (2 * i)))
+    posn = torch.arange(L, dtype=torch.float32)[:, None]
+    pe = torch.zeros(L, h)
+    pe[:, 0::2] = torch.sin(posn * div)
+    pe[:, 1::2] = torch.cos(posn * div)
+    return eng.AddBroadcastFn.apply(tensor, ops.cast(pe.to(tensor.device), tensor.dtype))
