@@ -70,6 +70,10 @@ typedef struct mk_gemm_desc {
   int32_t dtype;      /* MK_F32 or MK_BF16: type of A,B,C,R,bias */
 } mk_gemm_desc;
 int mk_gemm(const mk_gemm_desc* d, void* stream);
+/* Optional live timing of every mk_gemm launch with HIP events on the launch stream
+ * (bench.py roofline): begin, run, then end() synchronises and returns the sums. */
+int mk_prof_begin(void);
+int mk_prof_end(double* total_ms, double* total_flops, int64_t* launches);
 
 /* 2-D (batched) transpose out[z][c][r] = in[z][r][c]; elem_size 2 or 4. */
 int mk_transpose(const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in,

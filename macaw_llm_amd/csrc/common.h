@@ -27,6 +27,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MK_DEV __device__ __forceinline__
 
+// hipGetLastError() is sticky across *any* earlier runtime call of the process (e.g. a
+// hipEventQuery of PyTorch's allocator returning hipErrorNotReady), so every launch first
+// clears it and mk_check_launch() then reports only this launch's status.
+#define MK_LAUNCH(...)          \
+  do {                          \
+    (void)hipGetLastError();    \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
 static inline int mk_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MK_OK : MK_ERR_LAUNCH;

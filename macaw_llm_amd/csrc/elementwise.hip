@@ -319,11 +319,11 @@ extern "C" int mk_rope(void* x, const void* cos_t, const void* sin_t, const int3
                      ((reinterpret_cast<uintptr_t>(sin_t) & 15) == 0);
     if (vec) {
       const long total = (long)tokens * heads * (half / N);
-      hipLaunchKernelGGL((rope_kernel<T, true>), dim3(ew_grid(total)), dim3(256), 0, MK_ST, (T*)x,
+      MK_LAUNCH((rope_kernel<T, true>), dim3(ew_grid(total)), dim3(256), 0, MK_ST, (T*)x,
                          (const T*)cos_t, (const T*)sin_t, pos, tokens, heads, hd, (long)ld, sgn);
     } else {
       const long total = (long)tokens * heads * half;
-      hipLaunchKernelGGL((rope_kernel<T, false>), dim3(ew_grid(total)), dim3(256), 0, MK_ST, (T*)x,
+      MK_LAUNCH((rope_kernel<T, false>), dim3(ew_grid(total)), dim3(256), 0, MK_ST, (T*)x,
                          (const T*)cos_t, (const T*)sin_t, pos, tokens, heads, hd, (long)ld, sgn);
     }
   });
@@ -333,7 +333,7 @@ extern "C" int mk_rope(void* x, const void* cos_t, const void* sin_t, const int3
 extern "C" int mk_swiglu_fwd(const void* g, const void* u, void* a, int64_t n, int32_t dtype,
                              void* stream) {
   if (!g || !u || !a || n <= 0) return MK_ERR_BAD_ARG;
-  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((swiglu_fwd_kernel<T>),
+  MK_DISPATCH_T(dtype, MK_LAUNCH((swiglu_fwd_kernel<T>),
                                           dim3(ew_grid(n / VecIO<T>::N + 1)), dim3(256), 0, MK_ST,
                                           (const T*)g, (const T*)u, (T*)a, (long)n));
   return mk_check_launch();
@@ -341,7 +341,7 @@ extern "C" int mk_swiglu_fwd(const void* g, const void* u, void* a, int64_t n, i
 extern "C" int mk_swiglu_bwd(const void* g, const void* u, const void* da, void* dg, void* du,
                              int64_t n, int32_t dtype, void* stream) {
   if (!g || !u || !da || !dg || !du || n <= 0) return MK_ERR_BAD_ARG;
-  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((swiglu_bwd_kernel<T>),
+  MK_DISPATCH_T(dtype, MK_LAUNCH((swiglu_bwd_kernel<T>),
                                           dim3(ew_grid(n / VecIO<T>::N + 1)), dim3(256), 0, MK_ST,
                                           (const T*)g, (const T*)u, (const T*)da, (T*)dg, (T*)du,
                                           (long)n));
@@ -350,14 +350,14 @@ extern "C" int mk_swiglu_bwd(const void* g, const void* u, const void* da, void*
 extern "C" int mk_act_fwd(const void* x, void* y, int64_t n, int32_t act, int32_t dtype,
                           void* stream) {
   if (!x || !y || n <= 0) return MK_ERR_BAD_ARG;
-  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((act_fwd_kernel<T>), dim3(ew_grid(n)), dim3(256), 0,
+  MK_DISPATCH_T(dtype, MK_LAUNCH((act_fwd_kernel<T>), dim3(ew_grid(n)), dim3(256), 0,
                                           MK_ST, (const T*)x, (T*)y, (long)n, act));
   return mk_check_launch();
 }
 extern "C" int mk_act_bwd(const void* x_pre, const void* dy, void* dx, int64_t n, int32_t act,
                           int32_t dtype, void* stream) {
   if (!x_pre || !dy || !dx || n <= 0) return MK_ERR_BAD_ARG;
-  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(ew_grid(n)), dim3(256), 0,
+  MK_DISPATCH_T(dtype, MK_LAUNCH((act_bwd_kernel<T>), dim3(ew_grid(n)), dim3(256), 0,
                                           MK_ST, (const T*)x_pre, (const T*)dy, (T*)dx, (long)n,
                                           act));
   return mk_check_launch();
@@ -365,13 +365,13 @@ extern "C" int mk_act_bwd(const void* x_pre, const void* dy, void* dx, int64_t n
 extern "C" int mk_add(const void* a, const void* b, void* y, int64_t n, int64_t period,
                       int32_t dtype, void* stream) {
   if (!a || !b || !y || n <= 0) return MK_ERR_BAD_ARG;
-  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((add_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, MK_ST,
+  MK_DISPATCH_T(dtype, MK_LAUNCH((add_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, MK_ST,
                                           (const T*)a, (const T*)b, (T*)y, (long)n, (long)period));
   return mk_check_launch();
 }
 extern "C" int mk_fill(void* p, float v, int64_t n, int32_t dtype, void* stream) {
   if (!p || n <= 0) return MK_ERR_BAD_ARG;
-  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((fill_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, MK_ST,
+  MK_DISPATCH_T(dtype, MK_LAUNCH((fill_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, MK_ST,
                                           (T*)p, v, (long)n));
   return mk_check_launch();
 }
@@ -381,11 +381,11 @@ template <typename TI>
 int cast_from(const void* in, void* out, int32_t out_dtype, long n, hipStream_t st) {
   dim3 grid(ew_grid(n)), block(256);
   if (out_dtype == MK_F32)
-    hipLaunchKernelGGL((cast_kernel<TI, float>), grid, block, 0, st, (const TI*)in, (float*)out, n);
+    MK_LAUNCH((cast_kernel<TI, float>), grid, block, 0, st, (const TI*)in, (float*)out, n);
   else if (out_dtype == MK_BF16)
-    hipLaunchKernelGGL((cast_kernel<TI, bf16>), grid, block, 0, st, (const TI*)in, (bf16*)out, n);
+    MK_LAUNCH((cast_kernel<TI, bf16>), grid, block, 0, st, (const TI*)in, (bf16*)out, n);
   else if (out_dtype == MK_F16)
-    hipLaunchKernelGGL((cast_kernel<TI, _Float16>), grid, block, 0, st, (const TI*)in,
+    MK_LAUNCH((cast_kernel<TI, _Float16>), grid, block, 0, st, (const TI*)in,
                        (_Float16*)out, n);
   else return MK_ERR_UNSUPPORTED;
   return mk_check_launch();
@@ -404,7 +404,7 @@ extern "C" int mk_embedding_fwd(const void* table, const int64_t* ids, void* out
                                 int32_t dim, int64_t ld_out, int32_t vocab, int32_t dtype,
                                 void* stream) {
   if (!table || !ids || !out || tokens <= 0 || dim <= 0 || vocab <= 0) return MK_ERR_BAD_ARG;
-  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((embedding_fwd_kernel<T>), dim3(tokens), dim3(256), 0,
+  MK_DISPATCH_T(dtype, MK_LAUNCH((embedding_fwd_kernel<T>), dim3(tokens), dim3(256), 0,
                                           MK_ST, (const T*)table, ids, (T*)out, dim, (long)ld_out,
                                           vocab));
   return mk_check_launch();
@@ -413,7 +413,7 @@ extern "C" int mk_embedding_bwd(const void* dout, int64_t ld, const int64_t* ids
                                 int32_t tokens, int32_t dim, int32_t vocab, int64_t padding_idx,
                                 int32_t dtype, void* stream) {
   if (!dout || !ids || !dtable || tokens <= 0 || dim <= 0 || vocab <= 0) return MK_ERR_BAD_ARG;
-  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((embedding_bwd_kernel<T>), dim3(tokens), dim3(256), 0,
+  MK_DISPATCH_T(dtype, MK_LAUNCH((embedding_bwd_kernel<T>), dim3(tokens), dim3(256), 0,
                                           MK_ST, (const T*)dout, (long)ld, ids, (T*)dtable, tokens,
                                           dim, vocab, (long)padding_idx));
   return mk_check_launch();
@@ -426,7 +426,7 @@ extern "C" int mk_im2col1d(const void* x, void* out, int32_t B, int32_t C, int32
       ld_out < (int64_t)C * kw)
     return MK_ERR_BAD_ARG;
   const long total = (long)B * Lout * ld_out;
-  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((im2col1d_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
+  MK_DISPATCH_T(dtype, MK_LAUNCH((im2col1d_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
                                           MK_ST, (const T*)x, (T*)out, B, C, T_, kw, stride, pad,
                                           Lout, (long)sb, (long)sc, (long)st, (long)ld_out));
   return mk_check_launch();
@@ -437,7 +437,7 @@ extern "C" int mk_col2im1d(const void* dcols, void* dx, int32_t B, int32_t C, in
   if (!dcols || !dx || B <= 0 || C <= 0 || T_ <= 0 || kw <= 0 || stride <= 0 || Lout <= 0)
     return MK_ERR_BAD_ARG;
   const long total = (long)B * C * T_;
-  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((col2im1d_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
+  MK_DISPATCH_T(dtype, MK_LAUNCH((col2im1d_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
                                           MK_ST, (const T*)dcols, (T*)dx, B, C, T_, kw, stride, pad,
                                           Lout, (long)sb, (long)sc, (long)st, (long)ld_cols));
   return mk_check_launch();
@@ -447,7 +447,7 @@ extern "C" int mk_patchify(const void* img, void* out, int32_t B, int32_t C, int
   if (!img || !out || B <= 0 || C <= 0 || P <= 0 || H % P || W % P || ld_out < (int64_t)C * P * P)
     return MK_ERR_BAD_ARG;
   const long total = (long)B * (H / P) * (W / P) * ld_out;
-  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((patchify_kernel<T, true>), dim3(ew_grid(total)),
+  MK_DISPATCH_T(dtype, MK_LAUNCH((patchify_kernel<T, true>), dim3(ew_grid(total)),
                                           dim3(256), 0, MK_ST, (const T*)img, (T*)out, B, C, H, W,
                                           P, (long)ld_out));
   return mk_check_launch();
@@ -456,7 +456,7 @@ extern "C" int mk_unpatchify(const void* dcols, void* dimg, int32_t B, int32_t C
                              int32_t W, int32_t P, int64_t ld_cols, int32_t dtype, void* stream) {
   if (!dcols || !dimg || B <= 0 || C <= 0 || P <= 0 || H % P || W % P) return MK_ERR_BAD_ARG;
   const long total = (long)B * (H / P) * (W / P) * C * P * P;
-  MK_DISPATCH_T(dtype, hipLaunchKernelGGL((patchify_kernel<T, false>), dim3(ew_grid(total)),
+  MK_DISPATCH_T(dtype, MK_LAUNCH((patchify_kernel<T, false>), dim3(ew_grid(total)),
                                           dim3(256), 0, MK_ST, (const T*)dimg, (T*)dcols, B, C, H,
                                           W, P, (long)ld_cols));
   return mk_check_launch();
@@ -475,11 +475,11 @@ extern "C" int mk_copy2d(const void* src, void* dst, int32_t rows, int32_t cols,
   const long work = (long)rows * (vec ? row_bytes / 16 : cols);
   dim3 grid(ew_grid(work), 1, batch), block(256);
   if (elem_size == 2)
-    hipLaunchKernelGGL((copy2d_kernel<2>), grid, block, 0, MK_ST, (const char*)src, (char*)dst, rows,
+    MK_LAUNCH((copy2d_kernel<2>), grid, block, 0, MK_ST, (const char*)src, (char*)dst, rows,
                        row_bytes, (long)ld_src * es, (long)ld_dst * es, (long)s_src * es,
                        (long)s_dst * es, vec);
   else
-    hipLaunchKernelGGL((copy2d_kernel<4>), grid, block, 0, MK_ST, (const char*)src, (char*)dst, rows,
+    MK_LAUNCH((copy2d_kernel<4>), grid, block, 0, MK_ST, (const char*)src, (char*)dst, rows,
                        row_bytes, (long)ld_src * es, (long)ld_dst * es, (long)s_src * es,
                        (long)s_dst * es, vec);
   return mk_check_launch();

@@ -22,6 +22,8 @@
 // Replaces: nn.Linear / torch.matmul call sites listed in include/macaw_hip.h.
 #include "common.h"
 #include "../../include/macaw_hip.h"
+#include <utility>
+#include <vector>
 
 namespace {
 
@@ -398,6 +400,40 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
+
+// ---------------------------------------------------------------- profiler --
+// Optional per-launch HIP-event timing of mk_gemm on the launch stream, used by bench.py
+// for the `roofline` figure (kernel time measured live, same stream as the kernel).
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+}  // namespace
+
+extern "C" int mk_prof_begin(void) {
+  for (auto& r : g_prof) g_prof_pool.emplace_back(r.a, r.b);
+  g_prof.clear();
+  g_prof_on = true;
+  return MK_OK;
+}
+// Synchronises, sums (elapsed ms, flops, launches) over every mk_gemm since mk_prof_begin.
+extern "C" int mk_prof_end(double* total_ms, double* total_flops, int64_t* launches) {
+  g_prof_on = false;
+  double ms = 0.0, fl = 0.0;
+  for (auto& r : g_prof) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return MK_ERR_LAUNCH;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return MK_ERR_LAUNCH;
+    ms += t;
+    fl += r.flops;
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = (int64_t)g_prof.size();
+  return MK_OK;
+}
+
 extern "C" int mk_abi_version(void) { return MK_ABI_VERSION; }
 
 extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
@@ -416,6 +452,13 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
   g.alpha = d->alpha; g.bias_mode = d->bias_mode; g.act = d->act; g.accumulate = d->accumulate;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nbatch = d->nb1 * d->nb2;
+  ProfRec rec{};
+  if (g_prof_on) {
+    if (!g_prof_pool.empty()) { rec.a = g_prof_pool.back().first; rec.b = g_prof_pool.back().second; g_prof_pool.pop_back(); }
+    else { (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b); }
+    rec.flops = 2.0 * d->M * d->N * d->K * nbatch;
+    (void)hipEventRecord(rec.a, st);
+  }
   if (d->dtype == MK_BF16) {
     g.tiles_m = mk_cdiv(d->M, BM);
     g.tiles_n = mk_cdiv(d->N, BN);
@@ -435,7 +478,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);            \
       attr_done = true;                                                                     \
     }                                                                                       \
-    hipLaunchKernelGGL((gemm_bf16_kernel<AR, BR>), grid, block, shm, st, g);                \
+    MK_LAUNCH((gemm_bf16_kernel<AR, BR>), grid, block, shm, st, g);                \
   } while (0)
     if (!d->a_red_major && !d->b_red_major) MK_LAUNCH_BF16(false, false);
     else if (!d->a_red_major && d->b_red_major) MK_LAUNCH_BF16(false, true);
@@ -448,14 +491,15 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
     g.a_vec = g.b_vec = g.c_vec = 0;
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(256);
     if (!d->a_red_major && !d->b_red_major)
-      hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, st, g);
+      MK_LAUNCH((gemm_f32_kernel<false, false>), grid, block, 0, st, g);
     else if (!d->a_red_major && d->b_red_major)
-      hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, st, g);
+      MK_LAUNCH((gemm_f32_kernel<false, true>), grid, block, 0, st, g);
     else if (d->a_red_major && !d->b_red_major)
-      hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, st, g);
+      MK_LAUNCH((gemm_f32_kernel<true, false>), grid, block, 0, st, g);
     else
-      hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, st, g);
+      MK_LAUNCH((gemm_f32_kernel<true, true>), grid, block, 0, st, g);
   }
+  if (g_prof_on) { (void)hipEventRecord(rec.b, st); g_prof.push_back(rec); }
   return mk_check_launch();
 }
 
@@ -466,11 +510,11 @@ extern "C" int mk_transpose(const void* in, void* out, int32_t rows, int32_t col
   dim3 grid(mk_cdiv(cols, 64), mk_cdiv(rows, 64), batch), block(256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (elem_size == 2)
-    hipLaunchKernelGGL((transpose_kernel<unsigned short>), grid, block, 0, st,
+    MK_LAUNCH((transpose_kernel<unsigned short>), grid, block, 0, st,
                        (const unsigned short*)in, (unsigned short*)out, rows, cols, (long)ld_in,
                        (long)ld_out, (long)s_in, (long)s_out);
   else if (elem_size == 4)
-    hipLaunchKernelGGL((transpose_kernel<float>), grid, block, 0, st, (const float*)in,
+    MK_LAUNCH((transpose_kernel<float>), grid, block, 0, st, (const float*)in,
                        (float*)out, rows, cols, (long)ld_in, (long)ld_out, (long)s_in,
                        (long)s_out);
   else

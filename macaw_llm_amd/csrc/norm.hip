@@ -232,7 +232,7 @@ int rmsnorm_bwd_launch(const void* dy, const void* h, const void* w, const float
   const int ch = mk_cdiv(cols / N, 256);
   dim3 grid(nblk), block(256);
 #define MK_RB(CHV)                                                                             \
-  hipLaunchKernelGGL((rmsnorm_bwd_kernel<T, CHV>), grid, block, 0, st, (const T*)dy, (const T*)h, \
+  MK_LAUNCH((rmsnorm_bwd_kernel<T, CHV>), grid, block, 0, st, (const T*)dy, (const T*)h, \
                      (const T*)w, rstd, (const T*)dres, (T*)dx, dwp, rows, cols)
   if (ch <= 1) MK_RB(1);
   else if (ch <= 2) MK_RB(2);
@@ -250,7 +250,7 @@ int layernorm_bwd_launch(const void* dy, const void* x, const void* w, const flo
   const int ch = mk_cdiv(cols, 256);
   dim3 grid(nblk), block(256);
 #define MK_LB(CHV)                                                                          \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<T, CHV>), grid, block, 0, st, (const T*)dy,      \
+  MK_LAUNCH((layernorm_bwd_kernel<T, CHV>), grid, block, 0, st, (const T*)dy,      \
                      (const T*)x, (const T*)w, mean, rstd, (const T*)dres, (T*)dx, dwp, dbp, \
                      rows, cols)
   if (ch <= 1) MK_LB(1);
@@ -276,11 +276,11 @@ extern "C" int mk_rmsnorm_fwd(const void* x, const void* res, const void* w, voi
   dim3 grid(rows), block(256);
   if (dtype == MK_BF16) {
     if (cols % 8) return MK_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((rmsnorm_fwd_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x,
+    MK_LAUNCH((rmsnorm_fwd_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x,
                        (const bf16*)res, (const bf16*)w, (bf16*)h_out, (bf16*)y, rstd, cols, eps);
   } else if (dtype == MK_F32) {
     if (cols % 4) return MK_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((rmsnorm_fwd_kernel<float>), grid, block, 0, MK_ST, (const float*)x,
+    MK_LAUNCH((rmsnorm_fwd_kernel<float>), grid, block, 0, MK_ST, (const float*)x,
                        (const float*)res, (const float*)w, (float*)h_out, (float*)y, rstd, cols,
                        eps);
   } else return MK_ERR_UNSUPPORTED;
@@ -304,10 +304,10 @@ extern "C" int mk_layernorm_fwd(const void* x, const void* w, const void* b, voi
   if (!x || !w || !b || !y || !mean || !rstd || rows <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
   dim3 grid(rows), block(256);
   if (dtype == MK_BF16)
-    hipLaunchKernelGGL((layernorm_fwd_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x,
+    MK_LAUNCH((layernorm_fwd_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x,
                        (const bf16*)w, (const bf16*)b, (bf16*)y, mean, rstd, cols, eps);
   else if (dtype == MK_F32)
-    hipLaunchKernelGGL((layernorm_fwd_kernel<float>), grid, block, 0, MK_ST, (const float*)x,
+    MK_LAUNCH((layernorm_fwd_kernel<float>), grid, block, 0, MK_ST, (const float*)x,
                        (const float*)w, (const float*)b, (float*)y, mean, rstd, cols, eps);
   else return MK_ERR_UNSUPPORTED;
   return mk_check_launch();
@@ -333,10 +333,10 @@ extern "C" int mk_colsum_partials(const float* partial, void* out, int32_t nblk,
   if (!partial || !out || nblk <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
   dim3 grid(mk_cdiv(cols, 256)), block(256);
   if (dtype == MK_BF16)
-    hipLaunchKernelGGL((colsum_partials_kernel<bf16>), grid, block, 0, MK_ST, partial, (bf16*)out,
+    MK_LAUNCH((colsum_partials_kernel<bf16>), grid, block, 0, MK_ST, partial, (bf16*)out,
                        nblk, cols, accumulate);
   else if (dtype == MK_F32)
-    hipLaunchKernelGGL((colsum_partials_kernel<float>), grid, block, 0, MK_ST, partial,
+    MK_LAUNCH((colsum_partials_kernel<float>), grid, block, 0, MK_ST, partial,
                        (float*)out, nblk, cols, accumulate);
   else return MK_ERR_UNSUPPORTED;
   return mk_check_launch();
@@ -348,10 +348,10 @@ extern "C" int mk_colsum(const void* x, int64_t ld, void* out, float* ws, int32_
   if (!x || !out || !ws || nblk <= 0 || rows <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
   dim3 grid(mk_cdiv(cols, 256), nblk), block(256);
   if (dtype == MK_BF16)
-    hipLaunchKernelGGL((colsum_rows_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x, (long)ld,
+    MK_LAUNCH((colsum_rows_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x, (long)ld,
                        ws, rows, cols);
   else if (dtype == MK_F32)
-    hipLaunchKernelGGL((colsum_rows_kernel<float>), grid, block, 0, MK_ST, (const float*)x,
+    MK_LAUNCH((colsum_rows_kernel<float>), grid, block, 0, MK_ST, (const float*)x,
                        (long)ld, ws, rows, cols);
   else return MK_ERR_UNSUPPORTED;
   int rc = mk_check_launch();

@@ -248,7 +248,7 @@ int softmax_fwd_t(const void* scores, void* probs, void* probs_drop, const int32
   if (Lk <= 64 * 16) {
     dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
 #define MK_SW(E)                                                                               \
-  hipLaunchKernelGGL((softmax_fwd_wave_kernel<T, E>), grid, block, 0, st, (const T*)scores,     \
+  MK_LAUNCH((softmax_fwd_wave_kernel<T, E>), grid, block, 0, st, (const T*)scores,     \
                      (T*)probs, (T*)probs_drop, kmask, nrows, heads, Lq, Lk, ld, causal, p, seed)
     if (Lk <= 64) MK_SW(1);
     else if (Lk <= 128) MK_SW(2);
@@ -257,7 +257,7 @@ int softmax_fwd_t(const void* scores, void* probs, void* probs_drop, const int32
     else MK_SW(16);
 #undef MK_SW
   } else {
-    hipLaunchKernelGGL((softmax_fwd_block_kernel<T>), dim3((unsigned)nrows), dim3(256), 0, st,
+    MK_LAUNCH((softmax_fwd_block_kernel<T>), dim3((unsigned)nrows), dim3(256), 0, st,
                        (const T*)scores, (T*)probs, (T*)probs_drop, kmask, heads, Lq, Lk, ld,
                        causal, p, seed);
   }
@@ -290,10 +290,10 @@ extern "C" int mk_softmax_bwd(const void* probs, void* dprobs, int32_t nz, int32
   const int wpr = Lk <= 1024;
   dim3 grid((unsigned)(wpr ? (nrows + 3) / 4 : nrows)), block(256);
   if (dtype == MK_BF16)
-    hipLaunchKernelGGL((softmax_bwd_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)probs,
+    MK_LAUNCH((softmax_bwd_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)probs,
                        (bf16*)dprobs, Lk, (long)ld, scale, dropout_p, seed, nrows, wpr);
   else if (dtype == MK_F32)
-    hipLaunchKernelGGL((softmax_bwd_kernel<float>), grid, block, 0, MK_ST, (const float*)probs,
+    MK_LAUNCH((softmax_bwd_kernel<float>), grid, block, 0, MK_ST, (const float*)probs,
                        (float*)dprobs, Lk, (long)ld, scale, dropout_p, seed, nrows, wpr);
   else return MK_ERR_UNSUPPORTED;
   return mk_check_launch();
@@ -306,13 +306,13 @@ extern "C" int mk_cross_entropy(const void* logits, const int64_t* labels, float
       ld < V)
     return MK_ERR_BAD_ARG;
   if (dtype == MK_BF16)
-    hipLaunchKernelGGL((ce_fwd_kernel<bf16>), dim3(rows), dim3(256), 0, MK_ST, (const bf16*)logits,
+    MK_LAUNCH((ce_fwd_kernel<bf16>), dim3(rows), dim3(256), 0, MK_ST, (const bf16*)logits,
                        labels, row_loss, row_lse, V, (long)ld);
   else if (dtype == MK_F32)
-    hipLaunchKernelGGL((ce_fwd_kernel<float>), dim3(rows), dim3(256), 0, MK_ST,
+    MK_LAUNCH((ce_fwd_kernel<float>), dim3(rows), dim3(256), 0, MK_ST,
                        (const float*)logits, labels, row_loss, row_lse, V, (long)ld);
   else return MK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, MK_ST, row_loss, labels,
+  MK_LAUNCH(ce_reduce_kernel, dim3(1), dim3(256), 0, MK_ST, row_loss, labels,
                      loss_sum_cnt, rows, V);
   return mk_check_launch();
 }
@@ -325,11 +325,11 @@ extern "C" int mk_cross_entropy_bwd(const void* logits, void* dlogits, const int
       ld < V)
     return MK_ERR_BAD_ARG;
   if (dtype == MK_BF16)
-    hipLaunchKernelGGL((ce_bwd_kernel<bf16>), dim3(rows), dim3(256), 0, MK_ST, (const bf16*)logits,
+    MK_LAUNCH((ce_bwd_kernel<bf16>), dim3(rows), dim3(256), 0, MK_ST, (const bf16*)logits,
                        (bf16*)dlogits, labels, row_lse, loss_sum_cnt, grad_scale, grad_scale_dev, V,
                        (long)ld);
   else if (dtype == MK_F32)
-    hipLaunchKernelGGL((ce_bwd_kernel<float>), dim3(rows), dim3(256), 0, MK_ST,
+    MK_LAUNCH((ce_bwd_kernel<float>), dim3(rows), dim3(256), 0, MK_ST,
                        (const float*)logits, (float*)dlogits, labels, row_lse, loss_sum_cnt,
                        grad_scale, grad_scale_dev, V, (long)ld);
   else return MK_ERR_UNSUPPORTED;
@@ -347,11 +347,11 @@ extern "C" int mk_adamw(void* param, float* master, float* m, float* v, const vo
   if (nb > 4096) nb = 4096;
   dim3 grid((unsigned)nb), block(256);
   if (dtype == MK_BF16)
-    hipLaunchKernelGGL((adamw_kernel<bf16>), grid, block, 0, MK_ST, (bf16*)param, master, m, v,
+    MK_LAUNCH((adamw_kernel<bf16>), grid, block, 0, MK_ST, (bf16*)param, master, m, v,
                        (const bf16*)grad, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
                        grad_scale);
   else if (dtype == MK_F32)
-    hipLaunchKernelGGL((adamw_kernel<float>), grid, block, 0, MK_ST, (float*)param, master, m, v,
+    MK_LAUNCH((adamw_kernel<float>), grid, block, 0, MK_ST, (float*)param, master, m, v,
                        (const float*)grad, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
                        grad_scale);
   else return MK_ERR_UNSUPPORTED;

@@ -9,6 +9,12 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+# PyTorch must load ITS HIP runtime first: the library is linked against the system ROCm 7.2
+# libamdhip64 while torch bundles its own (ROCm 7.0 build).  If ours were dlopen'ed first the
+# process would end up with kernels registered in one runtime and torch's streams/allocations in
+# the other, and every launch fails.  Importing torch here makes the order deterministic.
+import torch  # noqa: F401
+
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libmacaw_hip.so"
 
@@ -44,6 +50,8 @@ _vp, _i32, _i64, _f32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_u
 SIGNATURES = {
     "mk_abi_version": [],
     "mk_gemm": [C.POINTER(GemmDesc), _vp],
+    "mk_prof_begin": [],
+    "mk_prof_end": [_vp, _vp, _vp],
     "mk_transpose": [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _vp],
     "mk_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp],
     "mk_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],

@@ -331,6 +331,23 @@ class MM_LLMs_Config(PretrainedConfig):
                  video_conv_kernel=36, video_conv_stride=30, audio_conv_kernel=240,
                  audio_conv_stride=220, clip_config=None, whisper_config=None, llm_config=None,
                  **kwargs):
+        # transformers >= 4.3x instantiates `cls()` with no arguments inside save_pretrained /
+        # to_diff_dict; the reference class would raise there.  Default sub-configs keep
+        # checkpoint round trips (run_clm_llms_inference.py:455) working.
+        clip_config = CLIPConfig() if clip_config is None else clip_config
+        whisper_config = WhisperConfig() if whisper_config is None else whisper_config
+        llm_config = LlamaConfig() if llm_config is None else llm_config
+        for name, sub, klass in (("clip_config", clip_config, CLIPConfig),
+                                 ("whisper_config", whisper_config, WhisperConfig),
+                                 ("llm_config", llm_config, LlamaConfig)):
+            if isinstance(sub, dict):
+                sub = klass.from_dict(sub)
+                if name == "clip_config":
+                    clip_config = sub
+                elif name == "whisper_config":
+                    whisper_config = sub
+                else:
+                    llm_config = sub
         self.image_config = clip_config
         self.audio_config = whisper_config
         self.llm_config = llm_config
@@ -366,6 +383,44 @@ class MM_LLMs_Config(PretrainedConfig):
         llm_config = LlamaConfig.from_dict(config_dict["llm_config"])
         return cls(clip_config=clip_config, whisper_config=whisper_config, llm_config=llm_config,
                    **kwargs)
+
+
+def build_prefix_layout(inputs: dict, lq: dict):
+    """Integer plumbing of modeling.py:977-1046 (bit-exact by construction, no float math).
+
+    lq maps each PRESENT modality to its number of aligned prefix tokens.  Returns
+      ids_full [B,S] int64 : token id at every position of the spliced sequence, -1 where the
+                             aligned modal features go.  Final order:
+                             [BOS][<image> f.. </image>][<audio> f.. </audio>][<video> f.. </video>][text 1:]
+      slots {name: (first feature position, Lq)}
+      attention_mask       : ones for the whole prefix PREPENDED to the text mask   (:1036-1040)
+      labels               : -100 for the whole prefix PREPENDED to the text labels (:1042-1046)
+    Unlike the reference this keeps integer dtypes when no modality is present (the reference's
+    empty `torch.tensor([])` is float and breaks the loss; tests/test_oracle.py)."""
+    ids = inputs["input_ids"].long()
+    B = ids.shape[0]
+    cols = [ids[:, :1]]
+    slots, pos, ignore = {}, 1, 0
+    for name in eng.MODALITIES:
+        if name not in lq:
+            continue
+        n = lq[name]
+        cols += [inputs[f"{name}_starts"].long().view(B, 1),
+                 torch.full((B, n), -1, dtype=torch.long, device=ids.device),
+                 inputs[f"{name}_ends"].long().view(B, 1)]
+        slots[name] = (pos + 1, n)
+        pos += n + 2
+        ignore += n + 2
+    cols.append(ids[:, 1:])
+    ids_full = torch.cat(cols, dim=1).contiguous()
+    attention_mask = labels = None
+    if inputs.get("attention_mask") is not None:
+        am = inputs["attention_mask"]
+        attention_mask = torch.cat([torch.ones((B, ignore), dtype=am.dtype, device=am.device), am], dim=1)
+    if inputs.get("labels") is not None:
+        lb = inputs["labels"]
+        labels = torch.cat([torch.full((B, ignore), -100, dtype=lb.dtype, device=lb.device), lb], dim=1)
+    return ids_full, slots, attention_mask, labels
 
 
 def _mha_params(m: nn.MultiheadAttention):
@@ -439,23 +494,12 @@ class MM_LLMs(PreTrainedModel):
         geom = dict(image=(cfg.image_conv_kernel, cfg.image_conv_stride),
                     audio=(cfg.audio_conv_kernel, cfg.audio_conv_stride),
                     video=(cfg.video_conv_kernel, cfg.video_conv_stride))
-        # integer plumbing: id map of the spliced sequence, -1 where modal features go
-        cols = [ids[:, :1]]
-        slots, pos, ignore = {}, 1, 0
+        lq = {}
         for name in eng.MODALITIES:
-            f = feats[name]
-            if f is None:
-                continue
-            kw, st = geom[name]
-            Lq = (f.shape[1] - kw) // st + 1
-            cols += [inputs[f"{name}_starts"].long().view(B, 1),
-                     torch.full((B, Lq), -1, dtype=torch.long, device=ids.device),
-                     inputs[f"{name}_ends"].long().view(B, 1)]
-            slots[name] = (pos + 1, Lq)
-            pos += Lq + 2
-            ignore += Lq + 2
-        cols.append(ids[:, 1:])
-        ids_full = torch.cat(cols, dim=1).contiguous()
+            if feats[name] is not None:
+                kw, st = geom[name]
+                lq[name] = (feats[name].shape[1] - kw) // st + 1
+        ids_full, slots, attention_mask, labels = build_prefix_layout(inputs, lq)
         self._step += 1
         p = 0.1 if self.training else 0.0
         meta = dict(ids_full=ids_full, slots=slots, heads=cfg.attention_heads * 2, geom=geom, p=p,
@@ -470,16 +514,6 @@ class MM_LLMs(PreTrainedModel):
                        *_mha_params(getattr(self, f"{name}_align_attention"))]
         text_embeddings = eng.PrefixAssembleFn.apply(E, meta, image_f, audio_f, video_f, *params)
 
-        if "attention_mask" in inputs and inputs["attention_mask"] is not None:
-            am = inputs["attention_mask"]
-            attention_mask = torch.cat([torch.ones((B, ignore), dtype=am.dtype, device=am.device), am], dim=1)
-        else:
-            attention_mask = None
-        if "labels" in inputs and inputs["labels"] is not None:
-            lb = inputs["labels"]
-            labels = torch.cat([torch.full((B, ignore), -100, dtype=lb.dtype, device=lb.device), lb], dim=1)
-        else:
-            labels = None
         return text_embeddings, attention_mask, labels
 
     # ----------------------------------------------------------- encoders ---

@@ -396,3 +396,14 @@ def adamw_(param, master, m, v, grad, lr, beta1, beta2, eps, wd, step, grad_scal
     lib = _L.load()
     _L.check(lib.mk_adamw(_p(param), _p(master), _p(m), _p(v), _p(grad), param.numel(), lr, beta1,
                           beta2, eps, wd, step, grad_scale, dt(param), _st()), "mk_adamw")
+
+
+def prof_begin():
+    _L.check(_L.load().mk_prof_begin(), "mk_prof_begin")
+
+
+def prof_end():
+    """returns (total_ms, total_flops, launches) of the mk_gemm launches since prof_begin"""
+    ms, fl, n = C.c_double(0), C.c_double(0), C.c_int64(0)
+    _L.check(_L.load().mk_prof_end(C.byref(ms), C.byref(fl), C.byref(n)), "mk_prof_end")
+    return ms.value, fl.value, n.value
