@@ -233,6 +233,8 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    if os.environ.get("MACAW_GEMM_REPORT") and rank == 0:
+        ops.prof_report(os.environ["MACAW_GEMM_REPORT"])
     gemm_ms, gemm_flops, gemm_n = ops.prof_end()
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:

@@ -74,6 +74,8 @@ int mk_gemm(const mk_gemm_desc* d, void* stream);
  * (bench.py roofline): begin, run, then end() synchronises and returns the sums. */
 int mk_prof_begin(void);
 int mk_prof_end(double* total_ms, double* total_flops, int64_t* launches);
+/* per-shape CSV breakdown (host path) of the launches since mk_prof_begin; call before end */
+int mk_prof_report(const char* path);
 
 /* 2-D (batched) transpose out[z][c][r] = in[z][r][c]; elem_size 2 or 4. */
 int mk_transpose(const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in,

@@ -168,14 +168,18 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const T* table, cons
     for (int c = threadIdx.x; c < dim; c += 256) dst[c] = src[c];
   }
 }
-// Deterministic scatter-add without atomics: the block of the FIRST occurrence
-// of a token id sums every later occurrence (fp32) and updates the row once.
+// Deterministic scatter-add without atomics: the block of the FIRST occurrence of a token id
+// collects the positions of every occurrence (parallel scan of the id list into LDS), sums
+// them in position order in fp32 and updates the table row once.
 template <typename T>
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const T* dout, long ld,
                                                             const int64_t* ids, T* dtable,
                                                             int tokens, int dim, int vocab,
                                                             long padding_idx) {
+  constexpr int MAXM = 1024;
   __shared__ int dup;
+  __shared__ int wcnt[4];
+  __shared__ int match[MAXM];
   const int t = blockIdx.x;
   const long id = ids[t];
   if (id < 0 || id >= vocab || id == padding_idx) return;
@@ -185,12 +189,33 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const T* dout, long 
     if (ids[j] == id) dup = 1;
   __syncthreads();
   if (dup) return;
-  for (int c0 = 0; c0 < dim; c0 += 256) {
-    const int c = c0 + threadIdx.x;
-    if (c >= dim) continue;
-    float acc = 0.f;
-    for (int j = t; j < tokens; ++j)
-      if (ids[j] == id) acc += to_f32<T>(dout[(long)j * ld + c]);
+  // ordered compaction of the later occurrences (ballot + prefix): match[] is sorted by position
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int nm = 0;
+  for (int base = t + 1; base < tokens; base += 256) {
+    const int j = base + threadIdx.x;
+    const bool hit = (j < tokens) && (ids[j] == id);
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) wcnt[wv] = __popcll(bal);
+    __syncthreads();
+    int off = nm;
+    for (int i = 0; i < wv; ++i) off += wcnt[i];
+    const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (hit) {
+      const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
+      if (k < MAXM) match[k] = j;
+    }
+    nm += tot;
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < dim; c += 256) {
+    float acc = to_f32<T>(dout[(long)t * ld + c]);
+    if (nm <= MAXM) {
+      for (int k = 0; k < nm; ++k) acc += to_f32<T>(dout[(long)match[k] * ld + c]);
+    } else {  // pathological: > MAXM repeats of one id, fall back to the linear scan
+      for (int j = t + 1; j < tokens; ++j)
+        if (ids[j] == id) acc += to_f32<T>(dout[(long)j * ld + c]);
+    }
     T* dp = dtable + id * dim + c;
     *dp = from_f32<T>(to_f32<T>(*dp) + acc);
   }

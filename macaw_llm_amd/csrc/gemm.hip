@@ -22,6 +22,8 @@
 // Replaces: nn.Linear / torch.matmul call sites listed in include/macaw_hip.h.
 #include "common.h"
 #include "../../include/macaw_hip.h"
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -64,6 +66,9 @@ MK_DEV void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
 
 // ------------------------------------------------------------------ bf16 --
 constexpr int BM = 128, BN = 128, BK = 64;
+#ifndef MK_GEMM_DEFAULT_CFG
+#define MK_GEMM_DEFAULT_CFG 5
+#endif
 constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
 
 // 8 bf16 from global with zero fill; `valid` = number of leading valid elements.
@@ -134,6 +139,32 @@ MK_DEV void tile_store(char* lds, const uint4 (&r)[4]) {
     *reinterpret_cast<uint4*>(lds + off) = r[i];
   }
 }
+// Interior tile: global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction,
+// no VGPR round trip and no ds_write pass).  The LDS destination of a wave instruction is
+// linear (base + lane*16), so the swizzle of the LDS image is applied to the per-lane SOURCE
+// address instead (cdna_hip_programming.md rule 21); each 128-B / 256-B global row segment is
+// still fetched whole.
+template <bool RED_MAJOR>
+MK_DEV void tile_glds(const bf16* base, long ld, int row0, int k0, char* lds_tile) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = w + 4 * i;  // 1-KiB piece of the 16-KiB tile
+    const bf16* gp;
+    if constexpr (!RED_MAJOR) {
+      const int row = p * 8 + (l >> 3);
+      const int kc = (l & 7) ^ ((row >> 1) & 7);
+      gp = base + (long)(row0 + row) * ld + k0 + kc * 8;
+    } else {
+      const int kr = p * 4 + (l >> 4);
+      const int mc = (l & 15) ^ (4 * (kr & 3));
+      gp = base + (long)(k0 + kr) * ld + row0 + mc * 8;
+    }
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gp,
+        (__attribute__((address_space(3))) void*)(lds_tile + p * 1024), 16, 0, 0);
+  }
+}
 // Fragment for v_mfma_f32_32x32x16_bf16: lane l holds row (l&31), k = 8*(l>>5)+j.
 template <bool RED_MAJOR>
 MK_DEV bf16x8 frag_load(const char* lds, int row_base, int ks) {
@@ -160,69 +191,11 @@ MK_DEV bf16x8 frag_load(const char* lds, int row_base, int ks) {
   }
 }
 
-template <bool A_RED, bool B_RED>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int tm, tn;
-  tile_coords(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
-  const int z = blockIdx.z, z1 = z / g.nb2, z2 = z - z1 * g.nb2;
-  const bf16* A = reinterpret_cast<const bf16*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
-  const bf16* B = reinterpret_cast<const bf16*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
-  bf16* C = reinterpret_cast<bf16*>(g.C) + z1 * g.sC1 + z2 * g.sC2;
-  const bf16* Rp = g.R ? reinterpret_cast<const bf16*>(g.R) + z1 * g.sR1 + z2 * g.sR2 : nullptr;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-  const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
-
-  // LDS map: [A0 | B0 | A1 | B1], 16 KiB each.
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int nk = (g.K + BK - 1) / BK;
-  uint4 ra[4], rb[4];
-  tile_load<A_RED>(A, g.lda, m0, 0, g.M, g.K, g.a_vec, ra);
-  tile_load<B_RED>(B, g.ldb, n0, 0, g.N, g.K, g.b_vec, rb);
-  tile_store<A_RED>(smem, ra);
-  tile_store<B_RED>(smem + TILE_BYTES, rb);
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = (kt + 1 < nk);
-    if (more) {
-      tile_load<A_RED>(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, g.a_vec, ra);
-      tile_load<B_RED>(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, g.b_vec, rb);
-    }
-    const char* la = smem + cur * (2 * TILE_BYTES);
-    const char* lb = la + TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 fm[2], fn[2];
-      fm[0] = frag_load<A_RED>(la, wm0, ks);
-      fm[1] = frag_load<A_RED>(la, wm0 + 32, ks);
-      fn[0] = frag_load<B_RED>(lb, wn0, ks);
-      fn[1] = frag_load<B_RED>(lb, wn0 + 32, ks);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn[j], fm[i], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      char* na = smem + (cur ^ 1) * (2 * TILE_BYTES);
-      tile_store<A_RED>(na, ra);
-      tile_store<B_RED>(na + TILE_BYTES, rb);
-    }
-    __syncthreads();
-  }
-
-  // Epilogue. D[i = n][j = m]: lane holds m = l&31, n = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// Epilogue for one wave's 64x64 accumulator block (2x2 fragments of 32x32).
+// D[i = n][j = m]: lane holds m = l&31, n = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+MK_DEV void wave_epilogue(const f32x16 (&acc)[2][2], const GemmArgs& g, bf16* C, const bf16* Rp,
+                          int m0, int n0, int wm0, int wn0) {
+  const int l = threadIdx.x & 63;
   const float alpha = g.alpha;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -282,6 +255,440 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
       }
     }
   }
+}
+
+template <bool A_RED, bool B_RED, bool GLDS>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tm, tn;
+  tile_coords(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
+  const int z = blockIdx.z, z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+  const bf16* A = reinterpret_cast<const bf16*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
+  const bf16* B = reinterpret_cast<const bf16*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
+  bf16* C = reinterpret_cast<bf16*>(g.C) + z1 * g.sC1 + z2 * g.sC2;
+  const bf16* Rp = g.R ? reinterpret_cast<const bf16*>(g.R) + z1 * g.sR1 + z2 * g.sR2 : nullptr;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
+
+  // LDS map: [A0 | B0 | A1 | B1], 16 KiB each.
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (g.K + BK - 1) / BK;
+  auto compute = [&](const char* la, const char* lb) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 fm[2], fn[2];
+      fm[0] = frag_load<A_RED>(la, wm0, ks);
+      fm[1] = frag_load<A_RED>(la, wm0 + 32, ks);
+      fn[0] = frag_load<B_RED>(lb, wn0, ks);
+      fn[1] = frag_load<B_RED>(lb, wn0 + 32, ks);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn[j], fm[i], acc[i][j], 0, 0, 0);
+    }
+  };
+  if constexpr (GLDS) {
+    // Pipeline: [wait tile kt landed; barrier] -> issue tile kt+1 (LDS-DMA, other buffer) ->
+    // 16 MFMAs on tile kt.  One barrier per K-tile, loads in flight during the MFMA block.
+    const bool a_rows = g.a_vec && (m0 + BM <= g.M);
+    const bool b_rows = g.b_vec && (n0 + BN <= g.N);
+    auto stage = [&](int kt, char* buf) {
+      const int k0 = kt * BK;
+      const bool kfull = (k0 + BK <= g.K);
+      if (a_rows && kfull) tile_glds<A_RED>(A, g.lda, m0, k0, buf);
+      else {
+        uint4 r[4];
+        tile_load<A_RED>(A, g.lda, m0, k0, g.M, g.K, g.a_vec, r);
+        tile_store<A_RED>(buf, r);
+      }
+      if (b_rows && kfull) tile_glds<B_RED>(B, g.ldb, n0, k0, buf + TILE_BYTES);
+      else {
+        uint4 r[4];
+        tile_load<B_RED>(B, g.ldb, n0, k0, g.N, g.K, g.b_vec, r);
+        tile_store<B_RED>(buf + TILE_BYTES, r);
+      }
+    };
+    stage(0, smem);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) stage(kt + 1, smem + (cur ^ 1) * (2 * TILE_BYTES));
+      const char* la = smem + cur * (2 * TILE_BYTES);
+      compute(la, la + TILE_BYTES);
+    }
+  } else {
+    uint4 ra[4], rb[4];
+    tile_load<A_RED>(A, g.lda, m0, 0, g.M, g.K, g.a_vec, ra);
+    tile_load<B_RED>(B, g.ldb, n0, 0, g.N, g.K, g.b_vec, rb);
+    tile_store<A_RED>(smem, ra);
+    tile_store<B_RED>(smem + TILE_BYTES, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const bool more = (kt + 1 < nk);
+      if (more) {
+        tile_load<A_RED>(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, g.a_vec, ra);
+        tile_load<B_RED>(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, g.b_vec, rb);
+      }
+      const char* la = smem + cur * (2 * TILE_BYTES);
+      compute(la, la + TILE_BYTES);
+      if (more) {
+        char* na = smem + (cur ^ 1) * (2 * TILE_BYTES);
+        tile_store<A_RED>(na, ra);
+        tile_store<B_RED>(na + TILE_BYTES, rb);
+      }
+      __syncthreads();
+    }
+  }
+
+  wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0);
+}
+
+// -------------------------------------------------- pipelined LDS-DMA kernel --
+// Generalisation of the kernel above: BMv x 128 x 64 block tile with BMv/64*2 waves (each wave
+// still 64x64), STAGES LDS buffers filled by global_load_lds, and a COUNTED vmcnt wait so that
+// with 3 stages the loads of tile kt+1 stay in flight across the barrier that publishes tile kt
+// (prefetch distance two K-tiles; cdna_hip_programming.md "Pipelining across barriers").
+template <int ROWS, int NT, bool RED_MAJOR>
+MK_DEV void ptile_slow(const bf16* base, long ld, int row0, int k0, int R, int K, bool vec,
+                       char* lds) {
+  constexpr int CH = ROWS * 8 / NT;
+  const int tid = threadIdx.x;
+#pragma unroll 1
+  for (int i = 0; i < CH; ++i) {
+    const int c = tid + NT * i;
+    uint4 v;
+    int off;
+    if constexpr (!RED_MAJOR) {
+      const int row = c >> 3, kc = c & 7;
+      const int gr = row0 + row, gk = k0 + kc * 8;
+      const int valid = (gr < R) ? min(max(K - gk, 0), 8) : 0;
+      v = load_chunk_slow(base + (long)gr * ld + gk, valid, vec);
+      off = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+    } else {
+      constexpr int CPR = ROWS / 8;  // 16-B chunks per k-row
+      const int kr = c / CPR, mc = c % CPR;
+      const int gk = k0 + kr, gr = row0 + mc * 8;
+      const int valid = (gk < K) ? min(max(R - gr, 0), 8) : 0;
+      v = load_chunk_slow(base + (long)gk * ld + gr, valid, vec);
+      off = kr * (ROWS * 2) + ((mc ^ (4 * (kr & 3))) << 4);
+    }
+    *reinterpret_cast<uint4*>(lds + off) = v;
+  }
+}
+template <int ROWS, int NW, bool RED_MAJOR>
+MK_DEV void ptile_glds(const bf16* base, long ld, int row0, int k0, char* lds) {
+  constexpr int PIECES = ROWS / 8;  // 1-KiB pieces of the ROWS x 64 bf16 tile
+  constexpr int PER = PIECES / NW;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int p = w + NW * i;
+    const bf16* gp;
+    if constexpr (!RED_MAJOR) {
+      const int row = p * 8 + (l >> 3);
+      const int kc = (l & 7) ^ ((row >> 1) & 7);
+      gp = base + (long)(row0 + row) * ld + k0 + kc * 8;
+    } else {
+      constexpr int CPR = ROWS / 8;
+      const int q = p * 64 + l;
+      const int kr = q / CPR, cc = q % CPR;
+      const int mc = cc ^ (4 * (kr & 3));
+      gp = base + (long)(k0 + kr) * ld + row0 + mc * 8;
+    }
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gp,
+        (__attribute__((address_space(3))) void*)(lds + p * 1024), 16, 0, 0);
+  }
+}
+template <int ROWS, bool RED_MAJOR>
+MK_DEV bf16x8 pfrag_load(const char* lds, int row_base, int ks) {
+  const int l = threadIdx.x & 63;
+  if constexpr (!RED_MAJOR) {
+    const int row = row_base + (l & 31);
+    const int kc = ks * 2 + (l >> 5);
+    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+  } else {
+    const int li = l & 15;
+    const int col = row_base + 16 * ((l >> 4) & 1) + 4 * (li & 3);
+    const int kr0 = ks * 16 + 8 * (l >> 5) + (li >> 2);
+    bf16x8 out;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int kr = kr0 + 4 * r;
+      const int off = kr * (ROWS * 2) + (((col >> 3) ^ (4 * (kr & 3))) << 4) + ((col & 7) << 1);
+      bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4*)(lds + off));
+      out[4 * r + 0] = t[0]; out[4 * r + 1] = t[1]; out[4 * r + 2] = t[2]; out[4 * r + 3] = t[3];
+    }
+    return out;
+  }
+}
+
+template <bool A_RED, bool B_RED, int BMv, int STAGES>
+__global__ __launch_bounds__(BMv * 2) void gemm_bf16_pipe_kernel(GemmArgs g) {
+  constexpr int NW = BMv / 64 * 2, NT = NW * 64;
+  constexpr int A_BYTES = BMv * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int G = (BMv / 8) / NW + 16 / NW;  // glds instructions per wave per stage
+  static_assert(G == 8 || G == 6, "vmcnt literals below");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tm, tn;
+  tile_coords(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
+  const int z = blockIdx.z, z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+  const bf16* A = reinterpret_cast<const bf16*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
+  const bf16* B = reinterpret_cast<const bf16*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
+  bf16* C = reinterpret_cast<bf16*>(g.C) + z1 * g.sC1 + z2 * g.sC2;
+  const bf16* Rp = g.R ? reinterpret_cast<const bf16*>(g.R) + z1 * g.sR1 + z2 * g.sR2 : nullptr;
+  const int m0 = tm * BMv, n0 = tn * BN;
+  const int w = threadIdx.x >> 6;
+  const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (g.K + BK - 1) / BK;
+  const bool rows_ok = g.a_vec && g.b_vec && (m0 + BMv <= g.M) && (n0 + BN <= g.N);  // block-uniform
+  auto fast = [&](int kt) { return rows_ok && ((kt + 1) * BK <= g.K); };
+  auto stage = [&](int kt) {
+    char* buf = smem + (kt % STAGES) * STAGE_BYTES;
+    const int k0 = kt * BK;
+    if (fast(kt)) {
+      ptile_glds<BMv, NW, A_RED>(A, g.lda, m0, k0, buf);
+      ptile_glds<BN, NW, B_RED>(B, g.ldb, n0, k0, buf + A_BYTES);
+    } else {
+      ptile_slow<BMv, NT, A_RED>(A, g.lda, m0, k0, g.M, g.K, g.a_vec, buf);
+      ptile_slow<BN, NT, B_RED>(B, g.ldb, n0, k0, g.N, g.K, g.b_vec, buf + A_BYTES);
+    }
+  };
+#pragma unroll
+  for (int s0 = 0; s0 < STAGES - 1; ++s0)
+    if (s0 < nk) stage(s0);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt must have landed; at most the (fast) tile kt+1 may stay in flight
+    bool keep = false;
+    if constexpr (STAGES == 3) keep = (kt + 1 < nk) && fast(kt + 1);
+    if (keep) {
+      if constexpr (G == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1);
+    const char* la = smem + (kt % STAGES) * STAGE_BYTES;
+    const char* lb = la + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 fm[2], fn[2];
+      fm[0] = pfrag_load<BMv, A_RED>(la, wm0, ks);
+      fm[1] = pfrag_load<BMv, A_RED>(la, wm0 + 32, ks);
+      fn[0] = pfrag_load<BN, B_RED>(lb, wn0, ks);
+      fn[1] = pfrag_load<BN, B_RED>(lb, wn0 + 32, ks);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn[j], fm[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0);
+}
+
+// ------------------------------------------------ v2: issue-lean LDS-DMA kernel --
+// PMC on the kernels above showed ~5.6 VALU instructions per MFMA (swizzle / 64-bit address
+// arithmetic recomputed every K-tile) and only ~40 % matrix-pipe occupancy: instruction issue,
+// not LDS or L2 bandwidth, was the limiter.  v2 keeps the 128x128x64 tile / 4 waves / 2
+// workgroups per CU, but moves every per-lane address computation out of the K loop:
+//   * global -> LDS by buffer_load_dwordx4 ... lds with a per-lane voffset computed ONCE and a
+//     scalar soffset advanced by SALU per K-tile (no VALU, no VGPR staging, no ds_write);
+//   * fragment LDS offsets precomputed per lane (K-major: 8 per operand; reduction-major: 2 per
+//     operand + immediates), the two LDS stages addressed through immediate offsets by
+//     unrolling the K loop by two;
+//   * M / N edge tiles need no predicates: K-major rows are clamped to the last valid row
+//     (garbage only reaches discarded outputs), reduction-major over-reads stay inside the
+//     buffer or hit the SRD bound (returns 0).
+// Requires 16-byte aligned operands and K % 64 == 0; anything else runs the generic kernel.
+template <bool RED_MAJOR>
+MK_DEV void v2_voffsets(int row0, int R, long ld, int w, int l, int (&voff)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = w + 4 * i;
+    if constexpr (!RED_MAJOR) {
+      const int row = p * 8 + (l >> 3);
+      const int kc = (l & 7) ^ ((row >> 1) & 7);
+      const int gr = min(row0 + row, R - 1) - row0;  // may be negative only if row0 >= R (never)
+      voff[i] = (int)((long)gr * ld * 2 + kc * 16);
+    } else {
+      const int kr = p * 4 + (l >> 4);
+      const int mc = (l & 15) ^ (4 * (kr & 3));
+      voff[i] = (int)((long)kr * ld * 2 + mc * 16);
+    }
+  }
+}
+template <bool RED_MAJOR>
+MK_DEV void v2_frag_offsets(int wrow0, int l, int (&off)[2][4]) {
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    if constexpr (!RED_MAJOR) {
+      const int row = wrow0 + f * 32 + (l & 31);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int kc = ks * 2 + (l >> 5);
+        off[f][ks] = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+      }
+    } else {
+      const int li = l & 15;
+      const int col = wrow0 + f * 32 + 16 * ((l >> 4) & 1) + 4 * (li & 3);
+      const int kr = 8 * (l >> 5) + (li >> 2);
+      off[f][0] = kr * 256 + (((col >> 3) ^ (4 * (kr & 3))) << 4) + ((col & 7) << 1);
+      off[f][1] = off[f][2] = off[f][3] = 0;
+    }
+  }
+}
+template <bool A_RED, bool B_RED>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tm, tn;
+  tile_coords(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
+  const int z = blockIdx.z, z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+  const bf16* A = reinterpret_cast<const bf16*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
+  const bf16* B = reinterpret_cast<const bf16*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
+  bf16* C = reinterpret_cast<bf16*>(g.C) + z1 * g.sC1 + z2 * g.sC2;
+  const bf16* Rp = g.R ? reinterpret_cast<const bf16*>(g.R) + z1 * g.sR1 + z2 * g.sR2 : nullptr;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int l = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
+
+  // buffer descriptors (tile-relative bases keep voffset small; num_records bounds the
+  // reduction-major over-read of the last K row)
+  const bf16* abase = A_RED ? A + m0 : A + (long)m0 * g.lda;
+  const bf16* bbase = B_RED ? B + n0 : B + (long)n0 * g.ldb;
+  const long a_bytes = A_RED ? ((long)(g.K - 1) * g.lda + (g.M - m0)) * 2
+                             : ((long)(min(g.M - m0, BM) - 1) * g.lda + g.K) * 2;
+  const long b_bytes = B_RED ? ((long)(g.K - 1) * g.ldb + (g.N - n0)) * 2
+                             : ((long)(min(g.N - n0, BN) - 1) * g.ldb + g.K) * 2;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)abase, 0, (int)min(a_bytes, 0x7fffffffL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)bbase, 0, (int)min(b_bytes, 0x7fffffffL), 0x00020000);
+  int voffA[4], voffB[4];
+  v2_voffsets<A_RED>(m0, g.M, g.lda, w, l, voffA);
+  v2_voffsets<B_RED>(n0, g.N, g.ldb, w, l, voffB);
+  const int stepA = A_RED ? (int)(BK * g.lda * 2) : BK * 2;  // bytes per K-tile
+  const int stepB = B_RED ? (int)(BK * g.ldb * 2) : BK * 2;
+  int offA[2][4], offB[2][4];
+  v2_frag_offsets<A_RED>(wm0, l, offA);
+  v2_frag_offsets<B_RED>(wn0, l, offB);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int sA = 0, sB = 0;  // scalar byte offsets of the next K-tile to issue
+  auto issue = [&](int stage) {
+    char* la = smem + stage * (2 * TILE_BYTES) + w * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsA, (__attribute__((address_space(3))) void*)(la + i * 4096), 16, voffA[i], sA, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsB, (__attribute__((address_space(3))) void*)(la + TILE_BYTES + i * 4096), 16, voffB[i],
+          sB, 0, 0);
+    sA += stepA;
+    sB += stepB;
+  };
+#define MK_V2_FRAG(RED, OFF, F, KS, BASE)                                                        \
+  [&]() -> bf16x8 {                                                                              \
+    if constexpr (!(RED)) {                                                                      \
+      return *reinterpret_cast<const bf16x8*>(smem + (BASE) + OFF[F][KS]);                       \
+    } else {                                                                                     \
+      bf16x8 o_;                                                                                 \
+      bf16x4 t0_ = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                     \
+          (__attribute__((address_space(3))) bf16x4*)(smem + (BASE) + (KS) * 16 * 256 + OFF[F][0])); \
+      bf16x4 t1_ = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                     \
+          (__attribute__((address_space(3))) bf16x4*)(smem + (BASE) + ((KS) * 16 + 4) * 256 + OFF[F][0])); \
+      o_[0] = t0_[0]; o_[1] = t0_[1]; o_[2] = t0_[2]; o_[3] = t0_[3];                            \
+      o_[4] = t1_[0]; o_[5] = t1_[1]; o_[6] = t1_[2]; o_[7] = t1_[3];                            \
+      return o_;                                                                                 \
+    }                                                                                            \
+  }()
+#define MK_V2_LOAD4(DST, KS, STAGE)                                                              \
+  do {                                                                                           \
+    DST[0] = MK_V2_FRAG(A_RED, offA, 0, KS, (STAGE) * 2 * TILE_BYTES);                           \
+    DST[1] = MK_V2_FRAG(A_RED, offA, 1, KS, (STAGE) * 2 * TILE_BYTES);                           \
+    DST[2] = MK_V2_FRAG(B_RED, offB, 0, KS, (STAGE) * 2 * TILE_BYTES + TILE_BYTES);              \
+    DST[3] = MK_V2_FRAG(B_RED, offB, 1, KS, (STAGE) * 2 * TILE_BYTES + TILE_BYTES);              \
+  } while (0)
+#define MK_V2_MFMA4(F)                                                                           \
+  do {                                                                                           \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[2], F[0], acc[0][0], 0, 0, 0);         \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[3], F[0], acc[0][1], 0, 0, 0);         \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[2], F[1], acc[1][0], 0, 0, 0);         \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[3], F[1], acc[1][1], 0, 0, 0);         \
+  } while (0)
+// fragments of k-step ks+1 are requested before the MFMAs of k-step ks (two register sets)
+#define MK_V2_COMPUTE(STAGE)                                                                     \
+  do {                                                                                           \
+    bf16x8 fa_[4], fb_[4];                                                                       \
+    MK_V2_LOAD4(fa_, 0, STAGE);                                                                  \
+    MK_V2_LOAD4(fb_, 1, STAGE);                                                                  \
+    MK_V2_MFMA4(fa_);                                                                            \
+    MK_V2_LOAD4(fa_, 2, STAGE);                                                                  \
+    MK_V2_MFMA4(fb_);                                                                            \
+    MK_V2_LOAD4(fb_, 3, STAGE);                                                                  \
+    MK_V2_MFMA4(fa_);                                                                            \
+    MK_V2_MFMA4(fb_);                                                                            \
+  } while (0)
+#define MK_V2_SYNC()                                          \
+  do {                                                        \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          \
+    __builtin_amdgcn_s_barrier();                             \
+    asm volatile("" ::: "memory");                            \
+  } while (0)
+
+  const int nk = g.K / BK;
+  issue(0);
+  for (int kt = 0; kt < nk; kt += 2) {
+    MK_V2_SYNC();
+    if (kt + 1 < nk) issue(1);
+    MK_V2_COMPUTE(0);
+    if (kt + 1 >= nk) break;
+    MK_V2_SYNC();
+    if (kt + 2 < nk) issue(0);
+    MK_V2_COMPUTE(1);
+  }
+#undef MK_V2_SYNC
+#undef MK_V2_COMPUTE
+#undef MK_V2_MFMA4
+#undef MK_V2_LOAD4
+#undef MK_V2_FRAG
+  wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0);
 }
 
 // ------------------------------------------------------------------- f32 --
@@ -405,7 +812,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 // Optional per-launch HIP-event timing of mk_gemm on the launch stream, used by bench.py
 // for the `roofline` figure (kernel time measured live, same stream as the kernel).
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; };
+struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, nb, layout, cfg; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
@@ -434,6 +841,32 @@ extern "C" int mk_prof_end(double* total_ms, double* total_flops, int64_t* launc
   return MK_OK;
 }
 
+// Per-shape breakdown of the launches since mk_prof_begin, written as CSV
+// (M,N,K,batch,layout,cfg,launches,total_ms,tflops).  Call before mk_prof_end.
+extern "C" int mk_prof_report(const char* path) {
+  FILE* f = fopen(path, "w");
+  if (!f) return MK_ERR_BAD_ARG;
+  struct Agg { int M, N, K, nb, layout, cfg; long n; double ms, fl; };
+  std::vector<Agg> aggs;
+  for (auto& r : g_prof) {
+    if (hipEventSynchronize(r.b) != hipSuccess) { fclose(f); return MK_ERR_LAUNCH; }
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, r.a, r.b);
+    bool found = false;
+    for (auto& a : aggs)
+      if (a.M == r.M && a.N == r.N && a.K == r.K && a.nb == r.nb && a.layout == r.layout && a.cfg == r.cfg) {
+        a.n++; a.ms += t; a.fl += r.flops; found = true; break;
+      }
+    if (!found) aggs.push_back({r.M, r.N, r.K, r.nb, r.layout, r.cfg, 1, (double)t, r.flops});
+  }
+  fprintf(f, "M,N,K,batch,layout,cfg,launches,total_ms,tflops\n");
+  for (auto& a : aggs)
+    fprintf(f, "%d,%d,%d,%d,%d,%d,%ld,%.4f,%.1f\n", a.M, a.N, a.K, a.nb, a.layout, a.cfg, a.n, a.ms,
+            a.ms > 0 ? a.fl / (a.ms * 1e-3) / 1e12 : 0.0);
+  fclose(f);
+  return MK_OK;
+}
+
 extern "C" int mk_abi_version(void) { return MK_ABI_VERSION; }
 
 extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
@@ -457,10 +890,30 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
     if (!g_prof_pool.empty()) { rec.a = g_prof_pool.back().first; rec.b = g_prof_pool.back().second; g_prof_pool.pop_back(); }
     else { (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b); }
     rec.flops = 2.0 * d->M * d->N * d->K * nbatch;
+    rec.M = d->M; rec.N = d->N; rec.K = d->K; rec.nb = nbatch;
+    rec.layout = d->a_red_major * 2 + d->b_red_major; rec.cfg = -1;
     (void)hipEventRecord(rec.a, st);
   }
   if (d->dtype == MK_BF16) {
-    g.tiles_m = mk_cdiv(d->M, BM);
+    // kernel configuration: 5 = v2 issue-lean LDS-DMA 128x128 (needs aligned operands, K%64==0),
+    // 0 = register-staged 128x128 (2 LDS buffers), 1 = LDS-DMA 128x128 x2,
+    // 2 = LDS-DMA 128x128 x3 stages, 3 = LDS-DMA 256x128 x2, 4 = LDS-DMA 256x128 x3 stages.
+    static const int env_cfg = [] {
+      const char* e = getenv("MK_GEMM_CFG");
+      return e ? atoi(e) : -1;
+    }();
+    int cfg = env_cfg >= 0 ? env_cfg : MK_GEMM_DEFAULT_CFG;
+    const bool v2_ok = aligned16(d->A) && aligned16(d->B) && (d->lda % 8 == 0) && (d->ldb % 8 == 0) &&
+                       (d->sA1 % 8 == 0) && (d->sA2 % 8 == 0) && (d->sB1 % 8 == 0) &&
+                       (d->sB2 % 8 == 0) && (d->K % BK == 0) &&
+                       ((long)d->K * d->lda * 2 < 0x7fffffffL) && ((long)d->K * d->ldb * 2 < 0x7fffffffL) &&
+                       ((long)BM * d->lda * 2 < 0x7fffffffL) && ((long)BN * d->ldb * 2 < 0x7fffffffL);
+    if (cfg == 5 && !v2_ok) cfg = 0;
+    rec.cfg = cfg;
+    if (cfg >= 3 && cfg != 5 && (d->M <= 128 || (long)mk_cdiv(d->M, 256) * mk_cdiv(d->N, BN) * nbatch < 256)) cfg -= 2;
+    const int bm = (cfg == 3 || cfg == 4) ? 256 : 128;
+    const int stages = (cfg == 2 || cfg == 4) ? 3 : 2;
+    g.tiles_m = mk_cdiv(d->M, bm);
     g.tiles_n = mk_cdiv(d->N, BN);
     g.a_vec = aligned16(d->A) && (d->lda % 8 == 0) && (d->sA1 % 8 == 0) && (d->sA2 % 8 == 0);
     g.b_vec = aligned16(d->B) && (d->ldb % 8 == 0) && (d->sB1 % 8 == 0) && (d->sB2 % 8 == 0);
@@ -468,23 +921,56 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
               (d->sC1 % 4 == 0) && (d->sC2 % 4 == 0) &&
               (!d->R || (((reinterpret_cast<uintptr_t>(d->R) & 7) == 0) && (d->ldr % 4 == 0) &&
                          (d->sR1 % 4 == 0) && (d->sR2 % 4 == 0)));
-    dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(256);
-    const size_t shm = 4 * TILE_BYTES;
-#define MK_LAUNCH_BF16(AR, BR)                                                              \
-  do {                                                                                      \
-    static bool attr_done = false;                                                          \
-    if (!attr_done) {                                                                       \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<AR, BR>),   \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);            \
-      attr_done = true;                                                                     \
-    }                                                                                       \
-    MK_LAUNCH((gemm_bf16_kernel<AR, BR>), grid, block, shm, st, g);                \
+    dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch);
+#define MK_PIPE(AR, BR, BMV, ST)                                                              \
+  do {                                                                                        \
+    constexpr int shm_ = (BMV * 128 + BN * 128) * ST;                                         \
+    static bool attr_done = false;                                                            \
+    if (!attr_done) {                                                                         \
+      (void)hipFuncSetAttribute(                                                              \
+          reinterpret_cast<const void*>(&gemm_bf16_pipe_kernel<AR, BR, BMV, ST>),             \
+          hipFuncAttributeMaxDynamicSharedMemorySize, shm_);                                  \
+      attr_done = true;                                                                       \
+    }                                                                                         \
+    MK_LAUNCH((gemm_bf16_pipe_kernel<AR, BR, BMV, ST>), grid, dim3(BMV * 2), shm_, st, g);    \
   } while (0)
-    if (!d->a_red_major && !d->b_red_major) MK_LAUNCH_BF16(false, false);
-    else if (!d->a_red_major && d->b_red_major) MK_LAUNCH_BF16(false, true);
-    else if (d->a_red_major && !d->b_red_major) MK_LAUNCH_BF16(true, false);
-    else MK_LAUNCH_BF16(true, true);
-#undef MK_LAUNCH_BF16
+#define MK_REG(AR, BR)                                                                        \
+  do {                                                                                        \
+    static bool attr_done = false;                                                            \
+    if (!attr_done) {                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<AR, BR, false>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);  \
+      attr_done = true;                                                                       \
+    }                                                                                         \
+    MK_LAUNCH((gemm_bf16_kernel<AR, BR, false>), grid, dim3(256), 4 * TILE_BYTES, st, g);     \
+  } while (0)
+#define MK_V2(AR, BR)                                                                         \
+  do {                                                                                        \
+    static bool attr_done = false;                                                            \
+    if (!attr_done) {                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v2_kernel<AR, BR>),  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);  \
+      attr_done = true;                                                                       \
+    }                                                                                         \
+    MK_LAUNCH((gemm_bf16_v2_kernel<AR, BR>), grid, dim3(256), 4 * TILE_BYTES, st, g);         \
+  } while (0)
+#define MK_LAYOUT(AR, BR)                                    \
+  do {                                                       \
+    if (cfg == 5) MK_V2(AR, BR);                             \
+    else if (cfg == 0) MK_REG(AR, BR);                       \
+    else if (cfg == 1) MK_PIPE(AR, BR, 128, 2);              \
+    else if (cfg == 2) MK_PIPE(AR, BR, 128, 3);              \
+    else if (cfg == 3) MK_PIPE(AR, BR, 256, 2);              \
+    else MK_PIPE(AR, BR, 256, 3);                            \
+  } while (0)
+    if (!d->a_red_major && !d->b_red_major) MK_LAYOUT(false, false);
+    else if (!d->a_red_major && d->b_red_major) MK_LAYOUT(false, true);
+    else if (d->a_red_major && !d->b_red_major) MK_LAYOUT(true, false);
+    else MK_LAYOUT(true, true);
+#undef MK_LAYOUT
+#undef MK_V2
+#undef MK_REG
+#undef MK_PIPE
   } else {
     g.tiles_m = mk_cdiv(d->M, FBM);
     g.tiles_n = mk_cdiv(d->N, FBN);

@@ -200,16 +200,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
   }
 }
 
-// out[c] (+)= sum_b partial[b][c]
+// out[c] (+)= sum_b partial[b][c].  Block = 32 columns x 8 row groups: every thread sums a
+// strided subset of the partial rows (independent loads), then the 8 groups meet in LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* partial, T* out,
                                                               int nblk, int cols, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float red[8][33];
+  const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(long)b * cols + c];
-  if (accumulate) s += to_f32<T>(out[c]);
-  out[c] = from_f32<T>(s);
+  if (c < cols)
+    for (int b = gy; b < nblk; b += 8) s += partial[(long)b * cols + c];
+  red[gy][cx] = s;
+  __syncthreads();
+  if (gy == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][cx];
+    if (accumulate) t += to_f32<T>(out[c]);
+    out[c] = from_f32<T>(t);
+  }
 }
 
 // partial[b][c] = sum over the block's row slab of x[r][c]
@@ -331,7 +341,7 @@ extern "C" int mk_layernorm_bwd(const void* dy, const void* x, const void* w, co
 extern "C" int mk_colsum_partials(const float* partial, void* out, int32_t nblk, int32_t cols,
                                   int32_t accumulate, int32_t dtype, void* stream) {
   if (!partial || !out || nblk <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
-  dim3 grid(mk_cdiv(cols, 256)), block(256);
+  dim3 grid(mk_cdiv(cols, 32)), block(256);
   if (dtype == MK_BF16)
     MK_LAUNCH((colsum_partials_kernel<bf16>), grid, block, 0, MK_ST, partial, (bf16*)out,
                        nblk, cols, accumulate);

@@ -19,138 +19,210 @@ MK_DEV uint32_t keep_thr(float p) {
   return k >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)k;
 }
 
-// One wave per row (Lk <= 64*MAXE), values held in registers.
-template <typename T, int MAXE>
+// masked logit of key k for query q (reference semantics, see header comment)
+template <typename T>
+MK_DEV float masked(float s, int k, int klim, const int32_t* km) {
+  return (k > klim || (km && km[k] == 0)) ? finfo_min<T>() : s;
+}
+
+// One wave per row, 16-byte vector loads, the whole row held in registers
+// (Lk <= 64 * N * MAXC: 2048 for bf16 at MAXC = 4).  Pad columns [Lk, ld) are written as 0.
+template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void softmax_fwd_wave_kernel(
     const T* scores, T* probs, T* probs_drop, const int32_t* kmask, long nrows, int heads, int Lq,
     int Lk, long ld, int causal, float p, uint64_t seed) {
+  constexpr int N = VecIO<T>::N;
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nrows) return;
   const int q = (int)(row % Lq);
-  const long z = row / Lq;
-  const long b = z / heads;
+  const long b = (row / Lq) / heads;
   const T* sr = scores + row * ld;
-  const int klim = causal ? q + (Lk - Lq) : Lk - 1;  // keys > klim are masked
-  const float lowest = finfo_min<T>();
-  float v[MAXE];
+  const int32_t* km = kmask ? kmask + b * Lk : nullptr;
+  const int klim = causal ? q + (Lk - Lq) : Lk - 1;
+  const int nch = (int)(ld / N);
+  float v[MAXC][N];
   float mx = -INFINITY;
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) {
-    const int k = lane + 64 * e;
-    v[e] = -INFINITY;
-    if (k < Lk) {
-      float s = to_f32<T>(sr[k]);
-      if (k > klim || (kmask && kmask[b * Lk + k] == 0)) s = lowest;
-      v[e] = s;
-      mx = fmaxf(mx, s);
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      VecIO<T>::load(sr + ch * N, v[c]);
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int k = ch * N + i;
+        v[c][i] = (k < Lk) ? masked<T>(v[c][i], k, klim, km) : -INFINITY;
+        mx = fmaxf(mx, v[c][i]);
+      }
     }
   }
   mx = wave_max(mx);
   float sum = 0.f;
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) {
-    const int k = lane + 64 * e;
-    if (k < Lk) { v[e] = __expf(v[e] - mx); sum += v[e]; }
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        v[c][i] = (ch * N + i < Lk) ? __expf(v[c][i] - mx) : 0.f;
+        sum += v[c][i];
+      }
+    }
   }
   sum = wave_sum(sum);
   const float inv = 1.f / sum;
   const uint32_t thr = keep_thr(p);
   const float dscale = p > 0.f ? 1.f / (1.f - p) : 1.f;
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) {
-    const int k = lane + 64 * e;
-    if (k < Lk) {
-      const T pv = from_f32<T>(v[e] * inv);
-      probs[row * ld + k] = pv;
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      float o[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) o[i] = rnd<T>(v[c][i] * inv);
+      VecIO<T>::store(probs + row * ld + ch * N, o);
       if (probs_drop) {
-        const bool keep = mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr);
-        probs_drop[row * ld + k] = keep ? from_f32<T>(to_f32<T>(pv) * dscale) : from_f32<T>(0.f);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const int k = ch * N + i;
+          o[i] = (k < Lk && mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr)) ? o[i] * dscale : 0.f;
+        }
+        VecIO<T>::store(probs_drop + row * ld + ch * N, o);
       }
     }
   }
 }
 
-// One 256-thread block per row (long rows, e.g. the 32,009-key alignment attention).
+// One 256-thread block per row (long rows, e.g. the 32,009-key alignment attention): three
+// vectorised passes (max, sum, write); the row (<= 64 KiB) stays in L2 between passes.
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_fwd_block_kernel(
     const T* scores, T* probs, T* probs_drop, const int32_t* kmask, int heads, int Lq, int Lk,
     long ld, int causal, float p, uint64_t seed) {
+  constexpr int N = VecIO<T>::N;
   __shared__ float red[16];
   const long row = blockIdx.x;
   const int q = (int)(row % Lq);
-  const long z = row / Lq;
-  const long b = z / heads;
+  const long b = (row / Lq) / heads;
   const T* sr = scores + row * ld;
+  const int32_t* km = kmask ? kmask + b * Lk : nullptr;
   const int klim = causal ? q + (Lk - Lq) : Lk - 1;
-  const float lowest = finfo_min<T>();
+  const int nch = (int)(ld / N);
   float mx = -INFINITY;
-  for (int k = threadIdx.x; k < Lk; k += 256) {
-    float s = to_f32<T>(sr[k]);
-    if (k > klim || (kmask && kmask[b * Lk + k] == 0)) s = lowest;
-    mx = fmaxf(mx, s);
+  for (int ch = threadIdx.x; ch < nch; ch += 256) {
+    float v[N];
+    VecIO<T>::load(sr + ch * N, v);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (ch * N + i < Lk) mx = fmaxf(mx, masked<T>(v[i], ch * N + i, klim, km));
   }
   mx = block_max<256>(mx, red);
   float sum = 0.f;
-  for (int k = threadIdx.x; k < Lk; k += 256) {
-    float s = to_f32<T>(sr[k]);
-    if (k > klim || (kmask && kmask[b * Lk + k] == 0)) s = lowest;
-    sum += __expf(s - mx);
+  for (int ch = threadIdx.x; ch < nch; ch += 256) {
+    float v[N];
+    VecIO<T>::load(sr + ch * N, v);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (ch * N + i < Lk) sum += __expf(masked<T>(v[i], ch * N + i, klim, km) - mx);
   }
   sum = block_sum<256>(sum, red);
   const float inv = 1.f / sum;
   const uint32_t thr = keep_thr(p);
   const float dscale = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  for (int k = threadIdx.x; k < Lk; k += 256) {
-    float s = to_f32<T>(sr[k]);
-    if (k > klim || (kmask && kmask[b * Lk + k] == 0)) s = lowest;
-    const T pv = from_f32<T>(__expf(s - mx) * inv);
-    probs[row * ld + k] = pv;
+  for (int ch = threadIdx.x; ch < nch; ch += 256) {
+    float v[N], o[N];
+    VecIO<T>::load(sr + ch * N, v);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int k = ch * N + i;
+      o[i] = (k < Lk) ? rnd<T>(__expf(masked<T>(v[i], k, klim, km) - mx) * inv) : 0.f;
+    }
+    VecIO<T>::store(probs + row * ld + ch * N, o);
     if (probs_drop) {
-      const bool keep = mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr);
-      probs_drop[row * ld + k] = keep ? from_f32<T>(to_f32<T>(pv) * dscale) : from_f32<T>(0.f);
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int k = ch * N + i;
+        o[i] = (k < Lk && mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr)) ? o[i] * dscale : 0.f;
+      }
+      VecIO<T>::store(probs_drop + row * ld + ch * N, o);
     }
   }
 }
 
 // dS = P .* (g - sum(g .* P)) * scale,  g = dP_drop .* keep/(1-p); in place on dprobs.
-template <typename T>
+// WAVE = true: one wave per row, row in registers; else one block per row, two passes.
+template <typename T, int MAXC, bool WAVE>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* probs, T* dprobs, int Lk,
                                                           long ld, float scale, float p,
-                                                          uint64_t seed, long nrows,
-                                                          int wave_per_row) {
+                                                          uint64_t seed, long nrows) {
+  constexpr int N = VecIO<T>::N;
   __shared__ float red[16];
   const uint32_t thr = keep_thr(p);
   const float dscale = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  if (wave_per_row) {
+  const int nch = (int)(ld / N);
+  if constexpr (WAVE) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
+    float pv[MAXC][N], gv[MAXC][N];
     float dot = 0.f;
-    for (int k = lane; k < Lk; k += 64) {
-      float g = to_f32<T>(dprobs[row * ld + k]);
-      if (p > 0.f) g = mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr) ? g * dscale : 0.f;
-      dot += g * to_f32<T>(probs[row * ld + k]);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        VecIO<T>::load(probs + row * ld + ch * N, pv[c]);
+        VecIO<T>::load(dprobs + row * ld + ch * N, gv[c]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const int k = ch * N + i;
+          float g = (k < Lk) ? gv[c][i] : 0.f;
+          if (p > 0.f) g = (k < Lk && mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr)) ? g * dscale : 0.f;
+          gv[c][i] = g;
+          dot += (k < Lk) ? g * pv[c][i] : 0.f;
+        }
+      }
     }
     dot = wave_sum(dot);
-    for (int k = lane; k < Lk; k += 64) {
-      float g = to_f32<T>(dprobs[row * ld + k]);
-      if (p > 0.f) g = mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr) ? g * dscale : 0.f;
-      dprobs[row * ld + k] = from_f32<T>(to_f32<T>(probs[row * ld + k]) * (g - dot) * scale);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        float o[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[i] = (ch * N + i < Lk) ? pv[c][i] * (gv[c][i] - dot) * scale : 0.f;
+        VecIO<T>::store(dprobs + row * ld + ch * N, o);
+      }
     }
   } else {
     const long row = blockIdx.x;
     float dot = 0.f;
-    for (int k = threadIdx.x; k < Lk; k += 256) {
-      float g = to_f32<T>(dprobs[row * ld + k]);
-      if (p > 0.f) g = mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr) ? g * dscale : 0.f;
-      dot += g * to_f32<T>(probs[row * ld + k]);
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {
+      float pv[N], gv[N];
+      VecIO<T>::load(probs + row * ld + ch * N, pv);
+      VecIO<T>::load(dprobs + row * ld + ch * N, gv);
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int k = ch * N + i;
+        if (k < Lk) {
+          float g = gv[i];
+          if (p > 0.f) g = mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr) ? g * dscale : 0.f;
+          dot += g * pv[i];
+        }
+      }
     }
     dot = block_sum<256>(dot, red);
-    for (int k = threadIdx.x; k < Lk; k += 256) {
-      float g = to_f32<T>(dprobs[row * ld + k]);
-      if (p > 0.f) g = mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr) ? g * dscale : 0.f;
-      dprobs[row * ld + k] = from_f32<T>(to_f32<T>(probs[row * ld + k]) * (g - dot) * scale);
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {
+      float pv[N], gv[N], o[N];
+      VecIO<T>::load(probs + row * ld + ch * N, pv);
+      VecIO<T>::load(dprobs + row * ld + ch * N, gv);
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int k = ch * N + i;
+        float g = gv[i];
+        if (p > 0.f) g = (k < Lk && mk_keep(seed, (uint64_t)row * (uint64_t)Lk + k, thr)) ? g * dscale : 0.f;
+        o[i] = (k < Lk) ? pv[i] * (g - dot) * scale : 0.f;
+      }
+      VecIO<T>::store(dprobs + row * ld + ch * N, o);
     }
   }
 }
@@ -244,22 +316,44 @@ template <typename T>
 int softmax_fwd_t(const void* scores, void* probs, void* probs_drop, const int32_t* kmask,
                   int nz, int heads, int Lq, int Lk, long ld, int causal, float p, uint64_t seed,
                   hipStream_t st) {
+  constexpr int N = VecIO<T>::N;
   const long nrows = (long)nz * Lq;
-  if (Lk <= 64 * 16) {
+  const long nch = ld / N;
+  if (nch <= 64 * 8) {
     dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
 #define MK_SW(E)                                                                               \
-  MK_LAUNCH((softmax_fwd_wave_kernel<T, E>), grid, block, 0, st, (const T*)scores,     \
-                     (T*)probs, (T*)probs_drop, kmask, nrows, heads, Lq, Lk, ld, causal, p, seed)
-    if (Lk <= 64) MK_SW(1);
-    else if (Lk <= 128) MK_SW(2);
-    else if (Lk <= 256) MK_SW(4);
-    else if (Lk <= 512) MK_SW(8);
-    else MK_SW(16);
+  MK_LAUNCH((softmax_fwd_wave_kernel<T, E>), grid, block, 0, st, (const T*)scores, (T*)probs,   \
+            (T*)probs_drop, kmask, nrows, heads, Lq, Lk, ld, causal, p, seed)
+    if (nch <= 64) MK_SW(1);
+    else if (nch <= 128) MK_SW(2);
+    else if (nch <= 256) MK_SW(4);
+    else MK_SW(8);
 #undef MK_SW
   } else {
     MK_LAUNCH((softmax_fwd_block_kernel<T>), dim3((unsigned)nrows), dim3(256), 0, st,
-                       (const T*)scores, (T*)probs, (T*)probs_drop, kmask, heads, Lq, Lk, ld,
-                       causal, p, seed);
+              (const T*)scores, (T*)probs, (T*)probs_drop, kmask, heads, Lq, Lk, ld, causal, p,
+              seed);
+  }
+  return mk_check_launch();
+}
+template <typename T>
+int softmax_bwd_t(const void* probs, void* dprobs, int nz, int Lq, int Lk, long ld, float scale,
+                  float p, uint64_t seed, hipStream_t st) {
+  constexpr int N = VecIO<T>::N;
+  const long nrows = (long)nz * Lq;
+  const long nch = ld / N;
+  if (nch <= 64 * 4) {
+    dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
+#define MK_SB(E)                                                                               \
+  MK_LAUNCH((softmax_bwd_kernel<T, E, true>), grid, block, 0, st, (const T*)probs, (T*)dprobs,  \
+            Lk, ld, scale, p, seed, nrows)
+    if (nch <= 64) MK_SB(1);
+    else if (nch <= 128) MK_SB(2);
+    else MK_SB(4);
+#undef MK_SB
+  } else {
+    MK_LAUNCH((softmax_bwd_kernel<T, 1, false>), dim3((unsigned)nrows), dim3(256), 0, st,
+              (const T*)probs, (T*)dprobs, Lk, ld, scale, p, seed, nrows);
   }
   return mk_check_launch();
 }
@@ -273,6 +367,9 @@ extern "C" int mk_softmax_fwd(const void* scores, void* probs, void* probs_drop,
     return MK_ERR_BAD_ARG;
   if (dropout_p < 0.f || dropout_p >= 1.f) return MK_ERR_BAD_ARG;
   if (dropout_p == 0.f) probs_drop = nullptr;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(scores) | reinterpret_cast<uintptr_t>(probs) |
+                       reinterpret_cast<uintptr_t>(probs_drop);
+  if ((al & 15) || ld % 8) return MK_ERR_UNSUPPORTED;  // rows must be 16-byte aligned, pitch % 8
   if (dtype == MK_BF16)
     return softmax_fwd_t<bf16>(scores, probs, probs_drop, kmask, nz, heads, Lq, Lk, ld, causal,
                                dropout_p, seed, MK_ST);
@@ -286,17 +383,13 @@ extern "C" int mk_softmax_bwd(const void* probs, void* dprobs, int32_t nz, int32
                               int64_t ld, float scale, float dropout_p, uint64_t seed,
                               int32_t dtype, void* stream) {
   if (!probs || !dprobs || nz <= 0 || Lq <= 0 || Lk <= 0 || ld < Lk) return MK_ERR_BAD_ARG;
-  const long nrows = (long)nz * Lq;
-  const int wpr = Lk <= 1024;
-  dim3 grid((unsigned)(wpr ? (nrows + 3) / 4 : nrows)), block(256);
+  const uintptr_t al = reinterpret_cast<uintptr_t>(probs) | reinterpret_cast<uintptr_t>(dprobs);
+  if ((al & 15) || ld % 8) return MK_ERR_UNSUPPORTED;
   if (dtype == MK_BF16)
-    MK_LAUNCH((softmax_bwd_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)probs,
-                       (bf16*)dprobs, Lk, (long)ld, scale, dropout_p, seed, nrows, wpr);
-  else if (dtype == MK_F32)
-    MK_LAUNCH((softmax_bwd_kernel<float>), grid, block, 0, MK_ST, (const float*)probs,
-                       (float*)dprobs, Lk, (long)ld, scale, dropout_p, seed, nrows, wpr);
-  else return MK_ERR_UNSUPPORTED;
-  return mk_check_launch();
+    return softmax_bwd_t<bf16>(probs, dprobs, nz, Lq, Lk, ld, scale, dropout_p, seed, MK_ST);
+  if (dtype == MK_F32)
+    return softmax_bwd_t<float>(probs, dprobs, nz, Lq, Lk, ld, scale, dropout_p, seed, MK_ST);
+  return MK_ERR_UNSUPPORTED;
 }
 
 extern "C" int mk_cross_entropy(const void* logits, const int64_t* labels, float* row_loss,

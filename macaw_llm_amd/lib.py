@@ -52,6 +52,7 @@ SIGNATURES = {
     "mk_gemm": [C.POINTER(GemmDesc), _vp],
     "mk_prof_begin": [],
     "mk_prof_end": [_vp, _vp, _vp],
+    "mk_prof_report": [C.c_char_p],
     "mk_transpose": [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _vp],
     "mk_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp],
     "mk_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],

@@ -402,6 +402,10 @@ def prof_begin():
     _L.check(_L.load().mk_prof_begin(), "mk_prof_begin")
 
 
+def prof_report(path: str):
+    _L.check(_L.load().mk_prof_report(path.encode()), "mk_prof_report")
+
+
 def prof_end():
     """returns (total_ms, total_flops, launches) of the mk_gemm launches since prof_begin"""
     ms, fl, n = C.c_double(0), C.c_double(0), C.c_int64(0)
