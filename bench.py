@@ -192,7 +192,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     from macaw_llm_amd import ops
-    from macaw_llm_amd.dp import GradSync
+    from macaw_llm_amd.train import OverlappedStep
     from macaw_llm_amd.factory import baseline_config, build_model, synthetic_inputs
     from macaw_llm_amd.optim import FusedAdamW
 
@@ -202,17 +202,15 @@ def main():
     model = build_model(cfg, dtype=torch.bfloat16, device=dev, seed=1234).train()
     params = [p for p in model.parameters() if p.requires_grad]
     opt = FusedAdamW(params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
-    sync = GradSync(params) if world > 1 else None
+    runtime = OverlappedStep(params, opt, overlap=not os.environ.get("MACAW_NO_OVERLAP"))
     B = args.batch_per_gpu
     inputs = synthetic_inputs(cfg, B, TEXT_LEN, modalities=("images", "audios"), seed=1 + rank, device=dev)
 
     def step():
-        opt.zero_grad()
+        runtime.begin()                      # zero grads, advance Adam's step counter
         loss = model(inputs=inputs).loss
-        loss.backward()
-        if sync is not None:
-            sync.finish()
-        opt.step()
+        loss.backward()                      # hooks: all-reduce (N>1) + AdamW behind the backward
+        runtime.finish()                     # small tensors, join streams
         return loss
 
     def fence():

@@ -68,6 +68,10 @@ typedef struct mk_gemm_desc {
   int32_t act;        /* 0 none, 1 gelu(erf), 2 quick_gelu (x*sigmoid(1.702x)) */
   int32_t accumulate; /* 1: C += result */
   int32_t dtype;      /* MK_F32 or MK_BF16: type of A,B,C,R,bias */
+  void* ws;           /* optional device scratch for the stream-K tail (fp32 partial tiles +
+                         arrival counters); NULL disables it. Must not be shared by GEMMs that
+                         run concurrently on different streams. */
+  int64_t ws_bytes;
 } mk_gemm_desc;
 int mk_gemm(const mk_gemm_desc* d, void* stream);
 /* Optional live timing of every mk_gemm launch with HIP events on the launch stream

@@ -40,6 +40,12 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int a_vec, b_vec;  // 1: 16-byte aligned vector loads allowed
   int c_vec;         // 1: vector C/R access allowed
+  // stream-K tail (v2 kernel only): blocks [0, dp_tiles) own whole tiles; the remaining
+  // tiles are cut into `split` K-pieces of `kt_per_piece` K-tiles, one block each.
+  int dp_tiles, split, kt_per_piece;
+  int ablate;      // debug only (MK_GEMM_ABLATE): 1 = skip global->LDS, 2 = skip barrier wait
+  float* ws;       // fp32 slabs [tail tile][piece][64 regs][256 threads]
+  int* counters;   // arrival counter per tail tile (zeroed by the launcher)
 };
 
 MK_DEV float apply_act(float v, int act) {
@@ -49,11 +55,16 @@ MK_DEV float apply_act(float v, int act) {
 }
 
 // XCD-aware + grouped tile order (cdna_hip_programming.md T1, bijective form).
-MK_DEV void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
-  const int nwg = tiles_m * tiles_n;
+MK_DEV int xcd_remap(int bid, int nwg) {
   const int xcd = bid & 7;
   const int q = nwg >> 3, r = nwg & 7;
-  int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+MK_DEV void tile_from_index(int wg, int tiles_m, int tiles_n, int& tm, int& tn);
+MK_DEV void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  tile_from_index(xcd_remap(bid, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+}
+MK_DEV void tile_from_index(int wg, int tiles_m, int tiles_n, int& tm, int& tn) {
   constexpr int GROUP_M = 8;
   const int per_group = GROUP_M * tiles_n;
   const int group = wg / per_group;
@@ -193,18 +204,19 @@ MK_DEV bf16x8 frag_load(const char* lds, int row_base, int ks) {
 
 // Epilogue for one wave's 64x64 accumulator block (2x2 fragments of 32x32).
 // D[i = n][j = m]: lane holds m = l&31, n = (reg&3) + 8*(reg>>2) + 4*(l>>5).
-MK_DEV void wave_epilogue(const f32x16 (&acc)[2][2], const GemmArgs& g, bf16* C, const bf16* Rp,
+template <int FM, int FN>
+MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* C, const bf16* Rp,
                           int m0, int n0, int wm0, int wn0) {
   const int l = threadIdx.x & 63;
   const float alpha = g.alpha;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < FM; ++i) {
     const int m = m0 + wm0 + i * 32 + (l & 31);
     if (m >= g.M) continue;
     float bias_m = 0.f;
     if (g.bias_mode == 2) bias_m = (float)reinterpret_cast<const bf16*>(g.bias)[m];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < FN; ++j) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + wn0 + j * 32 + 8 * q + 4 * (l >> 5);
@@ -568,7 +580,21 @@ template <bool A_RED, bool B_RED>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
-  tile_coords(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
+  int piece = -1, tail_idx = 0;
+  int kt_begin = 0, kt_end = g.K / BK;
+  {
+    const int bid = blockIdx.x;
+    if (bid < g.dp_tiles) {
+      tile_from_index(xcd_remap(bid, g.dp_tiles), g.tiles_m, g.tiles_n, tm, tn);
+    } else {
+      const int r = bid - g.dp_tiles;
+      tail_idx = r / g.split;
+      piece = r - tail_idx * g.split;
+      tile_from_index(g.dp_tiles + tail_idx, g.tiles_m, g.tiles_n, tm, tn);
+      kt_begin = piece * g.kt_per_piece;
+      kt_end = min(kt_end, kt_begin + g.kt_per_piece);
+    }
+  }
   const int z = blockIdx.z, z1 = z / g.nb2, z2 = z - z1 * g.nb2;
   const bf16* A = reinterpret_cast<const bf16*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
   const bf16* B = reinterpret_cast<const bf16*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
@@ -608,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  int sA = 0, sB = 0;  // scalar byte offsets of the next K-tile to issue
+  int sA = kt_begin * stepA, sB = kt_begin * stepB;  // scalar byte offsets of the next K-tile
   auto issue = [&](int stage) {
     char* la = smem + stage * (2 * TILE_BYTES) + w * 1024;
 #pragma unroll
@@ -672,22 +698,333 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
     asm volatile("" ::: "memory");                            \
   } while (0)
 
-  const int nk = g.K / BK;
-  issue(0);
-  for (int kt = 0; kt < nk; kt += 2) {
+  const int nk = kt_end - kt_begin;
+  // Pairs of K-tiles (stage 0 then stage 1) in a single-exit loop, odd tail afterwards: a
+  // mid-loop `break` made the compiler shuttle all 64 accumulator registers between two
+  // register sets every iteration (32 v_mov_b64 + MFMA-drain s_nops per pair).
+  if (nk > 0) issue(0);
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
     MK_V2_SYNC();
-    if (kt + 1 < nk) issue(1);
+    issue(1);
     MK_V2_COMPUTE(0);
-    if (kt + 1 >= nk) break;
     MK_V2_SYNC();
     if (kt + 2 < nk) issue(0);
     MK_V2_COMPUTE(1);
+  }
+  if (kt < nk) {
+    MK_V2_SYNC();
+    MK_V2_COMPUTE(0);
   }
 #undef MK_V2_SYNC
 #undef MK_V2_COMPUTE
 #undef MK_V2_MFMA4
 #undef MK_V2_LOAD4
 #undef MK_V2_FRAG
+  if (piece >= 0) {
+    // ---- stream-K tail: publish this piece's fp32 accumulators, last arriver reduces ----
+    // (placement-independent agent-scope release/acquire, cdna_hip_programming.md G16)
+    // Slabs are stored WRITE-THROUGH (sc1) so no L2 write-back fence is needed (the release
+    // fence flushes the whole XCD L2 and made the tail slower than the quantisation it fixes);
+    // every wave drains its stores, one lane bumps the tile's arrival counter, the last
+    // arriver does ONE agent-scope acquire and reads the slabs.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    float* slab0 = g.ws + (long)tail_idx * g.split * (64 * 256);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(slab0 + (long)piece * (64 * 256)), 0, 64 * 256 * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int e = (i * 2 + j) * 4 + q4;
+          u32x4 v;
+          v[0] = __float_as_uint(acc[i][j][4 * q4]); v[1] = __float_as_uint(acc[i][j][4 * q4 + 1]);
+          v[2] = __float_as_uint(acc[i][j][4 * q4 + 2]); v[3] = __float_as_uint(acc[i][j][4 * q4 + 3]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsS, (e * 256 + (int)threadIdx.x) * 16, 0, 16);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (threadIdx.x == 0) {
+      const int old = __hip_atomic_fetch_add(g.counters + tail_idx, 1, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+      *flag = (old == g.split - 1);
+    }
+    __syncthreads();
+    if (!*flag) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    // deterministic: sum the slabs in piece order regardless of who arrived last
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int pc = 0; pc < g.split; ++pc) {
+      const float* sl = slab0 + (long)pc * (64 * 256);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int e = (i * 2 + j) * 4 + q4;
+            const float4 v = *reinterpret_cast<const float4*>(sl + ((long)e * 256 + threadIdx.x) * 4);
+            acc[i][j][4 * q4] += v.x; acc[i][j][4 * q4 + 1] += v.y;
+            acc[i][j][4 * q4 + 2] += v.z; acc[i][j][4 * q4 + 3] += v.w;
+          }
+    }
+  }
+  wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0);
+}
+
+// ------------------------------------------------ v3: 256x256 tile, 8 waves of 128x64 --
+// Same issue-lean structure as v2 with twice the MFMA work per barrier and per LDS byte:
+// 8 waves (2 M x 4 N), wave tile 128x64 = 4x2 fragments (128 accumulator registers), LDS
+// 2 x 64 KiB, one workgroup per CU (two waves per SIMD).  Tile-count quantisation on the
+// 256-CU chip is absorbed by the stream-K tail.
+template <bool RED_MAJOR>
+MK_DEV void v3_voffsets(int row0, int R, long ld, int w, int l, int (&voff)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = w + 8 * i;  // 1-KiB piece (of 32) of the 256 x 64 tile
+    if constexpr (!RED_MAJOR) {
+      const int row = p * 8 + (l >> 3);
+      const int kc = (l & 7) ^ ((row >> 1) & 7);
+      const int gr = min(row0 + row, R - 1) - row0;
+      voff[i] = (int)((long)gr * ld * 2 + kc * 16);
+    } else {
+      const int q = p * 64 + l;
+      const int kr = q >> 5, cc = q & 31;
+      const int mc = cc ^ (4 * (kr & 3));
+      voff[i] = (int)((long)kr * ld * 2 + mc * 16);
+    }
+  }
+}
+template <bool RED_MAJOR, int NF>
+MK_DEV void v3_frag_offsets(int wrow0, int l, int (&off)[NF][4]) {
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    if constexpr (!RED_MAJOR) {
+      const int row = wrow0 + f * 32 + (l & 31);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int kc = ks * 2 + (l >> 5);
+        off[f][ks] = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+      }
+    } else {
+      const int li = l & 15;
+      const int col = wrow0 + f * 32 + 16 * ((l >> 4) & 1) + 4 * (li & 3);
+      const int kr = 8 * (l >> 5) + (li >> 2);
+      off[f][0] = kr * 512 + (((col >> 3) ^ (4 * (kr & 3))) << 4) + ((col & 7) << 1);
+      off[f][1] = off[f][2] = off[f][3] = 0;
+    }
+  }
+}
+
+template <bool A_RED, bool B_RED>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g) {
+  constexpr int BM3 = 256, BN3 = 256, FM = 4, FN = 2;
+  constexpr int A_BYTES = BM3 * 128, STAGE = 2 * A_BYTES;  // 64 KiB per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tm, tn;
+  int piece = -1, tail_idx = 0;
+  int kt_begin = 0, kt_end = g.K / BK;
+  {
+    const int bid = blockIdx.x;
+    if (bid < g.dp_tiles) {
+      tile_from_index(xcd_remap(bid, g.dp_tiles), g.tiles_m, g.tiles_n, tm, tn);
+    } else {
+      const int r = bid - g.dp_tiles;
+      tail_idx = r / g.split;
+      piece = r - tail_idx * g.split;
+      tile_from_index(g.dp_tiles + tail_idx, g.tiles_m, g.tiles_n, tm, tn);
+      kt_begin = piece * g.kt_per_piece;
+      kt_end = min(kt_end, kt_begin + g.kt_per_piece);
+    }
+  }
+  const int z = blockIdx.z, z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+  const bf16* A = reinterpret_cast<const bf16*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
+  const bf16* B = reinterpret_cast<const bf16*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
+  bf16* C = reinterpret_cast<bf16*>(g.C) + z1 * g.sC1 + z2 * g.sC2;
+  const bf16* Rp = g.R ? reinterpret_cast<const bf16*>(g.R) + z1 * g.sR1 + z2 * g.sR2 : nullptr;
+  const int m0 = tm * BM3, n0 = tn * BN3;
+  const int l = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm0 = (w >> 2) * 128, wn0 = (w & 3) * 64;
+
+  const bf16* abase = A_RED ? A + m0 : A + (long)m0 * g.lda;
+  const bf16* bbase = B_RED ? B + n0 : B + (long)n0 * g.ldb;
+  const long a_bytes = A_RED ? ((long)(g.K - 1) * g.lda + (g.M - m0)) * 2
+                             : ((long)(min(g.M - m0, BM3) - 1) * g.lda + g.K) * 2;
+  const long b_bytes = B_RED ? ((long)(g.K - 1) * g.ldb + (g.N - n0)) * 2
+                             : ((long)(min(g.N - n0, BN3) - 1) * g.ldb + g.K) * 2;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)abase, 0, (int)min(a_bytes, 0x7fffffffL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)bbase, 0, (int)min(b_bytes, 0x7fffffffL), 0x00020000);
+  int voffA[4], voffB[4];
+  v3_voffsets<A_RED>(m0, g.M, g.lda, w, l, voffA);
+  v3_voffsets<B_RED>(n0, g.N, g.ldb, w, l, voffB);
+  const int stepA = A_RED ? (int)(BK * g.lda * 2) : BK * 2;
+  const int stepB = B_RED ? (int)(BK * g.ldb * 2) : BK * 2;
+  int offA[FM][4], offB[FN][4];
+  v3_frag_offsets<A_RED, FM>(wm0, l, offA);
+  v3_frag_offsets<B_RED, FN>(wn0, l, offB);
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int sA = kt_begin * stepA, sB = kt_begin * stepB;
+  // one quarter of the next tile's LDS-DMA (1 A piece + 1 B piece per wave); the four quarters
+  // are interleaved with the four MFMA groups of the current tile so that the wave is never
+  // stuck issuing eight VMEM instructions back to back (ablation: the burst cost ~30 %).
+  auto issue_part = [&](int stage, int i) {
+    if (g.ablate & 1) return;
+    char* la = smem + stage * STAGE + w * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        rsA, (__attribute__((address_space(3))) void*)(la + i * 8192), 16, voffA[i], sA, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        rsB, (__attribute__((address_space(3))) void*)(la + A_BYTES + i * 8192), 16, voffB[i], sB, 0,
+        0);
+    if (i == 3) { sA += stepA; sB += stepB; }
+  };
+  auto issue = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_part(stage, i);
+  };
+#define MK_V3_FRAG(RED, OFF, F, KS, BASE)                                                        \
+  [&]() -> bf16x8 {                                                                              \
+    if constexpr (!(RED)) {                                                                      \
+      return *reinterpret_cast<const bf16x8*>(smem + (BASE) + OFF[F][KS]);                       \
+    } else {                                                                                     \
+      bf16x8 o_;                                                                                 \
+      bf16x4 t0_ = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                     \
+          (__attribute__((address_space(3))) bf16x4*)(smem + (BASE) + (KS) * 16 * 512 + OFF[F][0])); \
+      bf16x4 t1_ = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                     \
+          (__attribute__((address_space(3))) bf16x4*)(smem + (BASE) + ((KS) * 16 + 4) * 512 + OFF[F][0])); \
+      o_[0] = t0_[0]; o_[1] = t0_[1]; o_[2] = t0_[2]; o_[3] = t0_[3];                            \
+      o_[4] = t1_[0]; o_[5] = t1_[1]; o_[6] = t1_[2]; o_[7] = t1_[3];                            \
+      return o_;                                                                                 \
+    }                                                                                            \
+  }()
+#define MK_V3_LOAD(DST, KS, STAGE_)                                                              \
+  do {                                                                                           \
+    DST[0] = MK_V3_FRAG(A_RED, offA, 0, KS, (STAGE_) * STAGE);                                   \
+    DST[1] = MK_V3_FRAG(A_RED, offA, 1, KS, (STAGE_) * STAGE);                                   \
+    DST[2] = MK_V3_FRAG(A_RED, offA, 2, KS, (STAGE_) * STAGE);                                   \
+    DST[3] = MK_V3_FRAG(A_RED, offA, 3, KS, (STAGE_) * STAGE);                                   \
+    DST[4] = MK_V3_FRAG(B_RED, offB, 0, KS, (STAGE_) * STAGE + A_BYTES);                         \
+    DST[5] = MK_V3_FRAG(B_RED, offB, 1, KS, (STAGE_) * STAGE + A_BYTES);                         \
+  } while (0)
+#define MK_V3_MFMA(F)                                                                            \
+  do {                                                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                           \
+      acc[i_][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[4], F[i_], acc[i_][0], 0, 0, 0);    \
+      acc[i_][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[5], F[i_], acc[i_][1], 0, 0, 0);    \
+    }                                                                                            \
+  } while (0)
+#define MK_V3_COMPUTE(STAGE_, NEXT_)                                                             \
+  do {                                                                                           \
+    bf16x8 fa_[6], fb_[6];                                                                       \
+    MK_V3_LOAD(fa_, 0, STAGE_);                                                                  \
+    MK_V3_LOAD(fb_, 1, STAGE_);                                                                  \
+    if (NEXT_) issue_part(1 - (STAGE_), 0);                                                      \
+    MK_V3_MFMA(fa_);                                                                             \
+    MK_V3_LOAD(fa_, 2, STAGE_);                                                                  \
+    if (NEXT_) issue_part(1 - (STAGE_), 1);                                                      \
+    MK_V3_MFMA(fb_);                                                                             \
+    MK_V3_LOAD(fb_, 3, STAGE_);                                                                  \
+    if (NEXT_) issue_part(1 - (STAGE_), 2);                                                      \
+    MK_V3_MFMA(fa_);                                                                             \
+    if (NEXT_) issue_part(1 - (STAGE_), 3);                                                      \
+    MK_V3_MFMA(fb_);                                                                             \
+  } while (0)
+#define MK_V3_SYNC()                                          \
+  do {                                                        \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          \
+    if (!(g.ablate & 2)) __builtin_amdgcn_s_barrier();        \
+    asm volatile("" ::: "memory");                            \
+  } while (0)
+
+  const int nk = kt_end - kt_begin;
+  if (nk > 0) issue(0);
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    MK_V3_SYNC();
+    MK_V3_COMPUTE(0, true);
+    MK_V3_SYNC();
+    MK_V3_COMPUTE(1, kt + 2 < nk);
+  }
+  if (kt < nk) {
+    MK_V3_SYNC();
+    MK_V3_COMPUTE(0, false);
+  }
+#undef MK_V3_SYNC
+#undef MK_V3_COMPUTE
+#undef MK_V3_MFMA
+#undef MK_V3_LOAD
+#undef MK_V3_FRAG
+  if (piece >= 0) {
+    // stream-K tail, same protocol as v2 (write-through slabs, counter, one acquire)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int SLAB = FM * FN * 16 * 512;  // floats per piece
+    float* slab0 = g.ws + (long)tail_idx * g.split * SLAB;
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(slab0 + (long)piece * SLAB), 0, SLAB * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int e = (i * FN + j) * 4 + q4;
+          u32x4 v;
+          v[0] = __float_as_uint(acc[i][j][4 * q4]); v[1] = __float_as_uint(acc[i][j][4 * q4 + 1]);
+          v[2] = __float_as_uint(acc[i][j][4 * q4 + 2]); v[3] = __float_as_uint(acc[i][j][4 * q4 + 3]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsS, (e * 512 + (int)threadIdx.x) * 16, 0, 16);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (threadIdx.x == 0) {
+      const int old = __hip_atomic_fetch_add(g.counters + tail_idx, 1, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+      *flag = (old == g.split - 1);
+    }
+    __syncthreads();
+    if (!*flag) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int pc = 0; pc < g.split; ++pc) {
+      const float* sl = slab0 + (long)pc * SLAB;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int e = (i * FN + j) * 4 + q4;
+            const float4 v = *reinterpret_cast<const float4*>(sl + ((long)e * 512 + threadIdx.x) * 4);
+            acc[i][j][4 * q4] += v.x; acc[i][j][4 * q4 + 1] += v.y;
+            acc[i][j][4 * q4 + 2] += v.z; acc[i][j][4 * q4 + 3] += v.w;
+          }
+    }
+  }
   wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0);
 }
 
@@ -903,18 +1240,27 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
       return e ? atoi(e) : -1;
     }();
     int cfg = env_cfg >= 0 ? env_cfg : MK_GEMM_DEFAULT_CFG;
+    const auto fits = [&](bool red, long ld, int rows) {
+      const long span = red ? (long)d->K * ld * 2 : ((long)rows * ld + d->K) * 2;
+      return span < 0x7fffffffL;
+    };
     const bool v2_ok = aligned16(d->A) && aligned16(d->B) && (d->lda % 8 == 0) && (d->ldb % 8 == 0) &&
                        (d->sA1 % 8 == 0) && (d->sA2 % 8 == 0) && (d->sB1 % 8 == 0) &&
                        (d->sB2 % 8 == 0) && (d->K % BK == 0) &&
-                       ((long)d->K * d->lda * 2 < 0x7fffffffL) && ((long)d->K * d->ldb * 2 < 0x7fffffffL) &&
-                       ((long)BM * d->lda * 2 < 0x7fffffffL) && ((long)BN * d->ldb * 2 < 0x7fffffffL);
-    if (cfg == 5 && !v2_ok) cfg = 0;
+                       fits(d->a_red_major, d->lda, BM) && fits(d->b_red_major, d->ldb, BN);
+    if (cfg == 6) {  // 256x256 tiles only pay for big problems; otherwise the 128x128 v2 kernel
+      const bool big = d->M >= 512 && d->N >= 512 && d->K >= 512 && nbatch == 1 && d->ws &&
+                       fits(d->a_red_major, d->lda, 256) && fits(d->b_red_major, d->ldb, 256);
+      if (!big) cfg = 5;
+    }
+    if ((cfg == 5 || cfg == 6) && !v2_ok) cfg = 0;
     rec.cfg = cfg;
     if (cfg >= 3 && cfg != 5 && (d->M <= 128 || (long)mk_cdiv(d->M, 256) * mk_cdiv(d->N, BN) * nbatch < 256)) cfg -= 2;
-    const int bm = (cfg == 3 || cfg == 4) ? 256 : 128;
+    const int bm = (cfg == 3 || cfg == 4 || cfg == 6) ? 256 : 128;
+    const int bn = cfg == 6 ? 256 : BN;
     const int stages = (cfg == 2 || cfg == 4) ? 3 : 2;
     g.tiles_m = mk_cdiv(d->M, bm);
-    g.tiles_n = mk_cdiv(d->N, BN);
+    g.tiles_n = mk_cdiv(d->N, bn);
     g.a_vec = aligned16(d->A) && (d->lda % 8 == 0) && (d->sA1 % 8 == 0) && (d->sA2 % 8 == 0);
     g.b_vec = aligned16(d->B) && (d->ldb % 8 == 0) && (d->sB1 % 8 == 0) && (d->sB2 % 8 == 0);
     g.c_vec = ((reinterpret_cast<uintptr_t>(d->C) & 7) == 0) && (d->ldc % 4 == 0) &&
@@ -922,6 +1268,40 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
               (!d->R || (((reinterpret_cast<uintptr_t>(d->R) & 7) == 0) && (d->ldr % 4 == 0) &&
                          (d->sR1 % 4 == 0) && (d->sR2 % 4 == 0)));
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch);
+    g.dp_tiles = g.tiles_m * g.tiles_n;
+    g.split = 1;
+    g.kt_per_piece = 0;
+    g.ws = nullptr;
+    g.counters = nullptr;
+    static const int ablate = [] { const char* e = getenv("MK_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+    g.ablate = ablate;
+    if ((cfg == 5 || cfg == 6) && nbatch == 1 && d->ws && !getenv("MK_GEMM_NO_STREAMK")) {
+      static const int slots = [] {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus;
+      }() * (cfg == 6 ? 1 : 2);  // resident workgroups per CU: two 64-KiB v2 or one 128-KiB v3
+      const int T = g.tiles_m * g.tiles_n, nkt = d->K / BK;
+      const int R = T % slots;
+      int sp = R > 0 ? slots / R : 1;
+      if (sp > nkt / 2) sp = nkt / 2;  // at least two K-tiles per piece
+      if (sp > 64) sp = 64;
+      const long need = 4096 + (long)R * sp * (cfg == 6 ? 128 * 512 : 64 * 256) * 4;
+      if (R > 0 && sp >= 2 && need <= d->ws_bytes) {
+        g.dp_tiles = T - R;
+        g.split = sp;
+        g.kt_per_piece = (nkt + sp - 1) / sp;
+        // pieces that would start past the end get nk <= 0 and contribute zeros
+        g.counters = reinterpret_cast<int*>(d->ws);
+        g.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(d->ws) + 4096);
+        if (R * (int)sizeof(int) > 4096) { g.dp_tiles = T; g.split = 1; }
+        else {
+          (void)hipMemsetAsync(g.counters, 0, R * sizeof(int), st);
+          grid.x = g.dp_tiles + R * sp;
+        }
+      }
+    }
 #define MK_PIPE(AR, BR, BMV, ST)                                                              \
   do {                                                                                        \
     constexpr int shm_ = (BMV * 128 + BN * 128) * ST;                                         \
@@ -954,9 +1334,20 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
     }                                                                                         \
     MK_LAUNCH((gemm_bf16_v2_kernel<AR, BR>), grid, dim3(256), 4 * TILE_BYTES, st, g);         \
   } while (0)
+#define MK_V3(AR, BR)                                                                         \
+  do {                                                                                        \
+    static bool attr_done = false;                                                            \
+    if (!attr_done) {                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v3_kernel<AR, BR>),  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 131072);          \
+      attr_done = true;                                                                       \
+    }                                                                                         \
+    MK_LAUNCH((gemm_bf16_v3_kernel<AR, BR>), grid, dim3(512), 131072, st, g);                 \
+  } while (0)
 #define MK_LAYOUT(AR, BR)                                    \
   do {                                                       \
-    if (cfg == 5) MK_V2(AR, BR);                             \
+    if (cfg == 6) MK_V3(AR, BR);                             \
+    else if (cfg == 5) MK_V2(AR, BR);                        \
     else if (cfg == 0) MK_REG(AR, BR);                       \
     else if (cfg == 1) MK_PIPE(AR, BR, 128, 2);              \
     else if (cfg == 2) MK_PIPE(AR, BR, 128, 3);              \
@@ -969,6 +1360,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
     else MK_LAYOUT(true, true);
 #undef MK_LAYOUT
 #undef MK_V2
+#undef MK_V3
 #undef MK_REG
 #undef MK_PIPE
   } else {

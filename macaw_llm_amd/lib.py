@@ -41,6 +41,7 @@ class GemmDesc(C.Structure):
         ("alpha", C.c_float),
         ("bias_mode", C.c_int32), ("act", C.c_int32), ("accumulate", C.c_int32),
         ("dtype", C.c_int32),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
     ]
 
 

@@ -46,6 +46,19 @@ def _rowmajor(t: torch.Tensor) -> int:
 
 
 # ------------------------------------------------------------------- GEMM --
+_WS = {}
+WS_BYTES = 72 << 20
+
+
+def _workspace(device):
+    """per-(device, stream) scratch for the GEMM stream-K tail (partials + counters)"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = _WS[key] = torch.empty(WS_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
 def gemm_raw(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_red=False, b_red=False, R=None, ldr=0,
              bias=None, bias_mode=0, act=0, accumulate=False, alpha=1.0, nb1=1, nb2=1,
              sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), a_off=0, b_off=0, c_off=0, r_off=0):
@@ -71,6 +84,8 @@ def gemm_raw(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_red=False, b_red=False, R=No
     d.act = act
     d.accumulate = int(accumulate)
     d.dtype = dt(A)
+    ws = _workspace(A.device)
+    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
     if B.dtype != A.dtype or Cc.dtype != A.dtype:
         raise MacawHipError("gemm: mixed dtypes")
     _L.check(lib.mk_gemm(C.byref(d), _st()), "mk_gemm")

@@ -32,13 +32,19 @@ class FusedAdamW:
             p.grad = None
 
     @torch.no_grad()
+    def step_param(self, p, grad_scale: float = 1.0):
+        """update ONE parameter on the current stream with the current step_count
+        (used by train.OverlappedStep from gradient hooks)"""
+        if p.grad is None:
+            return
+        b1, b2 = self.betas
+        master, m, v = self._state(p)
+        g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+        ops.adamw_(p.data, master, m, v, g, self.lr, b1, b2, self.eps, self.weight_decay,
+                   self.step_count, grad_scale)
+
+    @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
         self.step_count += 1
-        b1, b2 = self.betas
         for p in self.params:
-            if p.grad is None:
-                continue
-            master, m, v = self._state(p)
-            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-            ops.adamw_(p.data, master, m, v, g, self.lr, b1, b2, self.eps, self.weight_decay,
-                       self.step_count, grad_scale)
+            self.step_param(p, grad_scale)

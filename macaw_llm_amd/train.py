@@ -1,0 +1,100 @@
+"""Training-step runtime: gradient averaging (RCCL) and the fused AdamW update both run
+*behind* the backward pass instead of after it.
+
+Backward on this chip is MFMA-bound (the GEMMs), the optimizer is HBM-bound (28 B per
+parameter) and the gradient all-reduce is xGMI-bound: three different resources.  As soon as
+autograd has written a parameter's gradient (post-accumulate hook — for a LLaMA layer all nine
+weight gradients appear together when that layer's backward block returns) we
+  1. (N > 1) launch its asynchronous all-reduce (RCCL runs on its own stream),
+  2. enqueue its AdamW update on a side HIP stream that waits for (1) — or, for N = 1, for an
+     event recorded on the compute stream —
+so collectives and optimizer traffic overlap the remaining backward GEMMs.  `finish()` flushes
+the coalesced small tensors and joins the streams.  Numerically identical to
+backward -> all-reduce -> optimizer.step().
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .optim import FusedAdamW
+
+
+class OverlappedStep:
+    def __init__(self, params: Iterable[torch.nn.Parameter], opt: FusedAdamW, process_group=None,
+                 small_threshold: int = 1 << 20, overlap: bool = True):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.opt = opt
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.small_threshold = small_threshold
+        self.overlap = overlap
+        dev = self.params[0].device
+        self.side = torch.cuda.Stream(device=dev) if (overlap and dev.type == "cuda") else None
+        self._small: List[torch.nn.Parameter] = []
+        self._pending = []  # (handle, param) for the non-overlapped / CPU path
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def begin(self):
+        """call once per step before backward: advances Adam's bias-correction step"""
+        self.opt.step_count += 1
+        for p in self.params:
+            p.grad = None
+
+    # ---- autograd hook: p.grad has just been written on the compute stream
+    def _on_grad(self, p):
+        g = p.grad
+        if g is None:
+            return
+        if self.world > 1 and g.numel() < self.small_threshold:
+            self._small.append(p)
+            return
+        handle = None
+        if self.world > 1:
+            op = dist.ReduceOp.AVG if g.is_cuda else dist.ReduceOp.SUM
+            handle = dist.all_reduce(g, op=op, group=self.group, async_op=True)
+        if self.side is not None:
+            cur = torch.cuda.current_stream(g.device)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            g.record_stream(self.side)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                if handle is not None:
+                    handle.wait()          # stream-ordered wait on the collective
+                self.opt.step_param(p)
+        else:
+            self._pending.append((handle, p))
+
+    def finish(self):
+        """flush small tensors, run whatever was not overlapped, join the side stream"""
+        if self.world > 1 and self._small:
+            flat = torch.cat([p.grad.reshape(-1) for p in self._small])
+            op = dist.ReduceOp.AVG if flat.is_cuda else dist.ReduceOp.SUM
+            dist.all_reduce(flat, op=op, group=self.group)
+            if op == dist.ReduceOp.SUM:
+                flat.div_(self.world)
+            off = 0
+            for p in self._small:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        for handle, p in self._pending:
+            if handle is not None:
+                handle.wait()
+                if not p.grad.is_cuda:
+                    p.grad.div_(self.world)
+            self.opt.step_param(p)
+        for p in self._small:
+            self.opt.step_param(p)
+        self._pending.clear()
+        self._small.clear()
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks.clear()
