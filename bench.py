@@ -202,7 +202,8 @@ def main():
     model = build_model(cfg, dtype=torch.bfloat16, device=dev, seed=1234).train()
     params = [p for p in model.parameters() if p.requires_grad]
     opt = FusedAdamW(params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
-    runtime = OverlappedStep(params, opt, overlap=not os.environ.get("MACAW_NO_OVERLAP"))
+    runtime = OverlappedStep(params, opt, overlap=not os.environ.get("MACAW_NO_OVERLAP"),
+                             overlap_optimizer=bool(os.environ.get("MACAW_OVERLAP_ADAMW")))
     B = args.batch_per_gpu
     inputs = synthetic_inputs(cfg, B, TEXT_LEN, modalities=("images", "audios"), seed=1 + rank, device=dev)
 

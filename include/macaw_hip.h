@@ -193,6 +193,17 @@ int mk_softmax_bwd(const void* probs, void* dprobs, int32_t nz, int32_t Lq, int3
                    int64_t ld, float scale, float dropout_p, uint64_t seed, int32_t dtype,
                    void* stream);
 
+/* Fused (flash) attention forward, bf16, head_dim 64 or 128: o = softmax(scale q k^T + mask) v
+ * per (batch, head) without materialising the scores (modeling.py:197-215 / HF encoder
+ * attention).  q/k/v/o are addressed as base + b*bs + token*ld + h*hd (elements); kmask
+ * [B, Lk] int32 (0 = masked) optional; causal masks key > query + (Lk - Lq); lse [B, H, Lq]
+ * f32 optional (log-sum-exp of the scaled, masked scores). */
+int mk_flash_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                      const int32_t* kmask, int32_t B, int32_t H, int32_t Lq, int32_t Lk,
+                      int32_t hd, int64_t q_ld, int64_t q_bs, int64_t k_ld, int64_t k_bs,
+                      int64_t v_ld, int64_t v_bs, int64_t o_ld, int64_t o_bs, float scale,
+                      int32_t causal, int32_t dtype, void* stream);
+
 /* Shifted cross-entropy (modeling.py:600-610). The caller passes labels already shifted
  * (row r predicts labels[r]; -100 = ignore).  row_loss[r] = lse_r - logit[r][label] (0 when
  * ignored), row_lse[r] kept for backward, loss_sum_cnt = {sum of row losses, number of valid

@@ -1,0 +1,211 @@
+// Fused (flash-style) attention forward for gfx950: softmax(scale * Q K^T + mask) V without
+// materialising the score matrix (at S = 2048 the fp32 score tensor is 537 MB per
+// sample per layer).  bf16 in/out, fp32 softmax state, head_dim 64 (CLIP / Whisper) or 128
+// (LLaMA).  Replaces modeling.py:197-215 and the HF encoder attention for the no-grad paths
+// (frozen towers, inference); the training path of the LLaMA layers keeps the GEMM + softmax
+// formulation until the fused backward lands.
+//
+// Work decomposition: block = 4 waves, each wave owns 32 query rows; the block walks the keys
+// in tiles of 64 staged in LDS (K: [key][d] XOR-swizzled for ds_read_b128; V: [key][d] read
+// back TRANSPOSED with ds_read_b64_tr_b16).  Both products use v_mfma_f32_32x32x16_bf16 with
+// the operands swapped so that a lane owns ONE query column:
+//   S^T[key][q] = K Q^T      lane (q = l&31, half = l>>5) holds 16 keys of its row
+//   O^T[d][q]  += V^T P^T    P^T fragments are exactly the lane's own S registers (the MFMA
+//                            k-slot <-> key mapping is chosen to match, no cross-lane shuffle)
+// Row max / sum need one __shfl_xor(.., 32) with the partner half.
+#include "common.h"
+#include "../../include/macaw_hip.h"
+
+namespace {
+
+struct FlashArgs {
+  const bf16* q; const bf16* k; const bf16* v; bf16* o; float* lse; const int32_t* kmask;
+  int B, H, Lq, Lk;
+  long q_ld, q_bs, k_ld, k_bs, v_ld, v_bs, o_ld, o_bs;
+  float scale;
+};
+
+template <int HD>
+MK_DEV int k_off(int row, int chunk) {  // K tile [64][HD] bf16, 16-B chunk swizzle
+  if constexpr (HD == 128) return row * 256 + ((chunk ^ (row & 15)) << 4);
+  else return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+template <int HD>
+MK_DEV int v_off(int key, int chunk) {  // V tile [64][HD] bf16, read through tr_b16
+  if constexpr (HD == 128) return key * 256 + ((chunk ^ (4 * (key & 3))) << 4);
+  else return key * 128 + ((chunk ^ (4 * ((key >> 1) & 1))) << 4);
+}
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void flash_fwd_kernel(FlashArgs a) {
+  constexpr int KT = 64;                 // keys per LDS tile
+  constexpr int NKD = HD / 16;           // MFMA k-steps over d for Q K^T
+  constexpr int NDB = HD / 32;           // 32-wide d blocks of the output
+  constexpr int CPR = HD / 8;            // 16-B chunks per row
+  __shared__ __attribute__((aligned(16))) char lds[2 * KT * HD * 2];
+  char* ldsK = lds;
+  char* ldsV = lds + KT * HD * 2;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int half = l >> 5, lq = l & 31;
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const int qg = q0 + lq;                // this lane's query row
+  const bf16* Q = a.q + (long)b * a.q_bs + (long)h * HD;
+  const bf16* K = a.k + (long)b * a.k_bs + (long)h * HD;
+  const bf16* V = a.v + (long)b * a.v_bs + (long)h * HD;
+  const int32_t* km = a.kmask ? a.kmask + (long)b * a.Lk : nullptr;
+
+  // Q fragments (B operand of K Q^T): lane holds Q[qg][16*kd + 8*half .. +8]
+  bf16x8 qf[NKD];
+#pragma unroll
+  for (int kd = 0; kd < NKD; ++kd) {
+    if (qg < a.Lq) qf[kd] = *reinterpret_cast<const bf16x8*>(Q + (long)qg * a.q_ld + 16 * kd + 8 * half);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[kd][e] = (bf16)0.f;
+    }
+  }
+  f32x16 oacc[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // keys this block has to visit (causal: up to the last query row of the block)
+  const int shift = a.Lk - a.Lq;         // query i may see keys <= i + shift
+  int k_end = a.Lk;
+  if (CAUSAL) k_end = min(a.Lk, blockIdx.x * 128 + 128 + shift);
+  const int ntiles = (k_end + KT - 1) / KT;
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int kbase = kt * KT;
+    __syncthreads();                     // previous tile fully consumed
+    // ---- stage K and V tiles (zero fill beyond Lk) ----
+#pragma unroll
+    for (int i = 0; i < (KT * CPR) / 256; ++i) {
+      const int c = threadIdx.x + 256 * i;
+      const int row = c / CPR, ch = c % CPR;
+      const int kg = kbase + row;
+      uint4 kv4 = make_uint4(0, 0, 0, 0), vv4 = make_uint4(0, 0, 0, 0);
+      if (kg < a.Lk) {
+        kv4 = *reinterpret_cast<const uint4*>(K + (long)kg * a.k_ld + ch * 8);
+        vv4 = *reinterpret_cast<const uint4*>(V + (long)kg * a.v_ld + ch * 8);
+      }
+      *reinterpret_cast<uint4*>(ldsK + k_off<HD>(row, ch)) = kv4;
+      *reinterpret_cast<uint4*>(ldsV + v_off<HD>(row, ch)) = vv4;
+    }
+    __syncthreads();
+    if (q0 >= a.Lq) continue;            // wave has no rows (still takes part in the barriers)
+
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      // ---- S^T = K Q^T for 32 keys x 32 queries ----
+      f32x16 s;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+      for (int kd = 0; kd < NKD; ++kd) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ldsK + k_off<HD>(sb * 32 + lq, 2 * kd + half));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], s, 0, 0, 0);
+      }
+      // ---- mask + online softmax (this lane: query qg, keys key(r)) ----
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kg = kbase + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        bool ok = kg < a.Lk;
+        if (CAUSAL) ok = ok && (kg <= qg + shift);
+        if (km) ok = ok && (km[kg < a.Lk ? kg : 0] != 0);
+        s[r] = ok ? s[r] * a.scale : -INFINITY;
+        mx = fmaxf(mx, s[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = (s[r] == -INFINITY) ? 0.f : __expf(s[r] - m_new);
+        ps += s[r];
+      }
+      ps += __shfl_xor(ps, 32, 64);
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+#pragma unroll
+      for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+      bf16x8 pf[2];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { pf[0][e] = (bf16)s[e]; pf[1][e] = (bf16)s[8 + e]; }
+      // ---- O^T += V^T P^T ----
+      const int li = l & 15;
+#pragma unroll
+      for (int d = 0; d < NDB; ++d) {
+        const int col = d * 32 + 16 * ((l >> 4) & 1) + 4 * (li & 3);   // d index of this lane group
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 vf;
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int key = sb * 32 + ks * 16 + 8 * r + 4 * half + (li >> 2);
+            const int off = v_off<HD>(key, col >> 3) + ((col & 7) << 1);
+            const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)(ldsV + off));
+            vf[4 * r] = t[0]; vf[4 * r + 1] = t[1]; vf[4 * r + 2] = t[2]; vf[4 * r + 3] = t[3];
+          }
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], oacc[d], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (qg >= a.Lq) return;
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  bf16* O = a.o + (long)b * a.o_bs + (long)qg * a.o_ld + (long)h * HD;
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      bf16x4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = (bf16)(oacc[d][4 * q4 + e] * inv);
+      *reinterpret_cast<bf16x4*>(O + d * 32 + 8 * q4 + 4 * half) = ov;
+    }
+  if (a.lse && half == 0)
+    a.lse[((long)b * a.H + h) * a.Lq + qg] = (l_run > 0.f) ? m_run + __logf(l_run) : -INFINITY;
+}
+
+}  // namespace
+
+extern "C" int mk_flash_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                                 const int32_t* kmask, int32_t B, int32_t H, int32_t Lq,
+                                 int32_t Lk, int32_t hd, int64_t q_ld, int64_t q_bs, int64_t k_ld,
+                                 int64_t k_bs, int64_t v_ld, int64_t v_bs, int64_t o_ld,
+                                 int64_t o_bs, float scale, int32_t causal, int32_t dtype,
+                                 void* stream) {
+  if (!q || !k || !v || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return MK_ERR_BAD_ARG;
+  if (dtype != MK_BF16 || (hd != 64 && hd != 128)) return MK_ERR_UNSUPPORTED;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
+                       reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(o);
+  if ((al & 15) || (q_ld % 8) || (k_ld % 8) || (v_ld % 8) || (o_ld % 8) || (q_bs % 8) ||
+      (k_bs % 8) || (v_bs % 8) || (o_bs % 8))
+    return MK_ERR_UNSUPPORTED;
+  FlashArgs a;
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (bf16*)o;
+  a.lse = lse; a.kmask = kmask;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
+  a.q_ld = q_ld; a.q_bs = q_bs; a.k_ld = k_ld; a.k_bs = k_bs; a.v_ld = v_ld; a.v_bs = v_bs;
+  a.o_ld = o_ld; a.o_bs = o_bs;
+  a.scale = scale;
+  dim3 grid(mk_cdiv(Lq, 128), H, B), block(256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hd == 128) {
+    if (causal) MK_LAUNCH((flash_fwd_kernel<128, true>), grid, block, 0, st, a);
+    else MK_LAUNCH((flash_fwd_kernel<128, false>), grid, block, 0, st, a);
+  } else {
+    if (causal) MK_LAUNCH((flash_fwd_kernel<64, true>), grid, block, 0, st, a);
+    else MK_LAUNCH((flash_fwd_kernel<64, false>), grid, block, 0, st, a);
+  }
+  return mk_check_launch();
+}

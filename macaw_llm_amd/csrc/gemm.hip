@@ -43,6 +43,7 @@ struct GemmArgs {
   // stream-K tail (v2 kernel only): blocks [0, dp_tiles) own whole tiles; the remaining
   // tiles are cut into `split` K-pieces of `kt_per_piece` K-tiles, one block each.
   int dp_tiles, split, kt_per_piece;
+  int lin_batch;   // 1: batch index is folded into the linear tile index (grid.z == 1)
   int ablate;      // debug only (MK_GEMM_ABLATE): 1 = skip global->LDS, 2 = skip barrier wait
   float* ws;       // fp32 slabs [tail tile][piece][64 regs][256 threads]
   int* counters;   // arrival counter per tail tile (zeroed by the launcher)
@@ -580,22 +581,29 @@ template <bool A_RED, bool B_RED>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
-  int piece = -1, tail_idx = 0;
+  int piece = -1, tail_idx = 0, zlin = 0;
   int kt_begin = 0, kt_end = g.K / BK;
   {
     const int bid = blockIdx.x;
+    int t;
     if (bid < g.dp_tiles) {
-      tile_from_index(xcd_remap(bid, g.dp_tiles), g.tiles_m, g.tiles_n, tm, tn);
+      t = xcd_remap(bid, g.dp_tiles);
     } else {
       const int r = bid - g.dp_tiles;
       tail_idx = r / g.split;
       piece = r - tail_idx * g.split;
-      tile_from_index(g.dp_tiles + tail_idx, g.tiles_m, g.tiles_n, tm, tn);
+      t = g.dp_tiles + tail_idx;
       kt_begin = piece * g.kt_per_piece;
       kt_end = min(kt_end, kt_begin + g.kt_per_piece);
     }
+    if (g.lin_batch) {
+      const int per = g.tiles_m * g.tiles_n;
+      zlin = t / per;
+      t -= zlin * per;
+    }
+    tile_from_index(t, g.tiles_m, g.tiles_n, tm, tn);
   }
-  const int z = blockIdx.z, z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+  const int z = g.lin_batch ? zlin : (int)blockIdx.z, z1 = z / g.nb2, z2 = z - z1 * g.nb2;
   const bf16* A = reinterpret_cast<const bf16*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
   const bf16* B = reinterpret_cast<const bf16*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
   bf16* C = reinterpret_cast<bf16*>(g.C) + z1 * g.sC1 + z2 * g.sC2;
@@ -1269,20 +1277,21 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
                          (d->sR1 % 4 == 0) && (d->sR2 % 4 == 0)));
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch);
     g.dp_tiles = g.tiles_m * g.tiles_n;
+    g.lin_batch = 0;
     g.split = 1;
     g.kt_per_piece = 0;
     g.ws = nullptr;
     g.counters = nullptr;
     static const int ablate = [] { const char* e = getenv("MK_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     g.ablate = ablate;
-    if ((cfg == 5 || cfg == 6) && nbatch == 1 && d->ws && !getenv("MK_GEMM_NO_STREAMK")) {
+    if ((cfg == 5 || (cfg == 6 && nbatch == 1)) && d->ws && !getenv("MK_GEMM_NO_STREAMK")) {
       static const int slots = [] {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return cus;
       }() * (cfg == 6 ? 1 : 2);  // resident workgroups per CU: two 64-KiB v2 or one 128-KiB v3
-      const int T = g.tiles_m * g.tiles_n, nkt = d->K / BK;
+      const int T = g.tiles_m * g.tiles_n * nbatch, nkt = d->K / BK;
       const int R = T % slots;
       int sp = R > 0 ? slots / R : 1;
       if (sp > nkt / 2) sp = nkt / 2;  // at least two K-tiles per piece
@@ -1299,6 +1308,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
         else {
           (void)hipMemsetAsync(g.counters, 0, R * sizeof(int), st);
           grid.x = g.dp_tiles + R * sp;
+          if (nbatch > 1) { g.lin_batch = 1; grid.z = 1; }
         }
       }
     }

@@ -36,11 +36,20 @@ class TDesc:
         self.t, self.ld, self.bs, self.off = t, ld, bs, off
 
 
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
 def attention_fwd(q: TDesc, k: TDesc, v: TDesc, o: TDesc, B, H, Lq, Lk, hd, scale, kmask=None,
-                  causal=False, p=0.0, seed=0):
+                  causal=False, p=0.0, seed=0, Lk_pad=None):
     """o[b,h] = dropout(softmax(scale * q[b,h] k[b,h]^T + mask)) v[b,h].
-    Returns (probs, probs_dropped|None) with rows [B*H*Lq, pad8(Lk)]."""
-    Lp = pad8(Lk)
+    Returns (probs, probs_dropped|None) with rows [B*H*Lq, Lp].
+
+    Lk_pad (multiple of 64, optional): the caller guarantees that rows [Lk, Lk_pad) of the K/V
+    buffers exist and are ZERO; the key reduction then runs over Lk_pad so the long-K products
+    take the aligned LDS-DMA GEMM with a batched stream-K split of the long reduction."""
+    Lp = Lk_pad if Lk_pad is not None else pad8(Lk)
+    Kred = Lk_pad if Lk_pad is not None else Lk
     dev, dtype = q.t.device, q.t.dtype
     scores = torch.empty((B * H * Lq, Lp), dtype=dtype, device=dev)
     ops.gemm_raw(q.t, k.t, scores, Lq, Lk, hd, q.ld, k.ld, Lp, nb1=B, nb2=H, sA=(q.bs, hd),
@@ -48,15 +57,16 @@ def attention_fwd(q: TDesc, k: TDesc, v: TDesc, o: TDesc, B, H, Lq, Lk, hd, scal
     probs, pd = ops.softmax_fwd(scores, B * H, H, Lq, Lk, Lp, kmask=kmask, causal=causal,
                                 dropout_p=p, seed=seed, probs=scores, want_dropped=p > 0.0)
     pa = pd if pd is not None else probs
-    ops.gemm_raw(pa, v.t, o.t, Lq, hd, Lk, Lp, v.ld, o.ld, b_red=True, nb1=B, nb2=H,
+    ops.gemm_raw(pa, v.t, o.t, Lq, hd, Kred, Lp, v.ld, o.ld, b_red=True, nb1=B, nb2=H,
                  sA=(H * Lq * Lp, Lq * Lp), sB=(v.bs, hd), sC=(o.bs, hd), b_off=v.off, c_off=o.off)
     return probs, pd
 
 
 def attention_bwd(do: TDesc, q: TDesc, k: TDesc, v: TDesc, probs, pd, dq: TDesc, dk: TDesc,
-                  dv: TDesc, B, H, Lq, Lk, hd, scale, p=0.0, seed=0):
+                  dv: TDesc, B, H, Lq, Lk, hd, scale, p=0.0, seed=0, Lk_pad=None):
     """Given do = dL/do, writes dq, dk, dv (same layouts as q, k, v)."""
-    Lp = pad8(Lk)
+    Lp = Lk_pad if Lk_pad is not None else pad8(Lk)
+    Kred = Lk_pad if Lk_pad is not None else Lk
     dP = torch.empty_like(probs)
     sP = (H * Lq * Lp, Lq * Lp)
     # dP = do v^T
@@ -66,13 +76,18 @@ def attention_bwd(do: TDesc, q: TDesc, k: TDesc, v: TDesc, probs, pd, dq: TDesc,
     pa = pd if pd is not None else probs
     ops.gemm_raw(pa, do.t, dv.t, Lk, hd, Lq, Lp, do.ld, dv.ld, a_red=True, b_red=True, nb1=B, nb2=H,
                  sA=sP, sB=(do.bs, hd), sC=(dv.bs, hd), b_off=do.off, c_off=dv.off)
-    # dS = softmax'(P, dP) * scale   (in place)
+    # dS = softmax'(P, dP) * scale   (in place; pad columns come out as zeros)
     ops.softmax_bwd_(probs, dP, B * H, Lq, Lk, Lp, scale=scale, dropout_p=p, seed=seed)
     # dq = dS k ; dk = dS^T q
-    ops.gemm_raw(dP, k.t, dq.t, Lq, hd, Lk, Lp, k.ld, dq.ld, b_red=True, nb1=B, nb2=H, sA=sP,
+    ops.gemm_raw(dP, k.t, dq.t, Lq, hd, Kred, Lp, k.ld, dq.ld, b_red=True, nb1=B, nb2=H, sA=sP,
                  sB=(k.bs, hd), sC=(dq.bs, hd), b_off=k.off, c_off=dq.off)
     ops.gemm_raw(dP, q.t, dk.t, Lk, hd, Lq, Lp, q.ld, dk.ld, a_red=True, b_red=True, nb1=B, nb2=H,
                  sA=sP, sB=(q.bs, hd), sC=(dk.bs, hd), b_off=q.off, c_off=dk.off)
+
+
+def flash_ok(dtype, hd) -> bool:
+    """the fused attention kernels cover bf16 with head_dim 64 / 128"""
+    return dtype == torch.bfloat16 and hd in (64, 128)
 
 
 def _c2(x: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
@@ -100,17 +115,24 @@ class LlamaLayerFn(torch.autograd.Function):
         ops.rope_(q, cos, sin, pos, H, hd)
         ops.rope_(k, cos, sin, pos, H, hd)
         att = torch.empty((M, D), dtype=x.dtype, device=x.device)
-        probs, _ = attention_fwd(TDesc(q, D, S * D), TDesc(k, D, S * D), TDesc(v, D, S * D),
-                                 TDesc(att, D, S * D), B, H, S, S, hd, 1.0 / math.sqrt(hd),
-                                 kmask=kmask, causal=True)
+        grad_mode = any(ctx.needs_input_grad)
+        if not grad_mode and flash_ok(x.dtype, hd):
+            ops.flash_attn_fwd(q, k, v, att, B, H, S, S, hd, D, S * D, D, S * D, D, S * D, D, S * D,
+                               1.0 / math.sqrt(hd), kmask=kmask, causal=True)
+            probs = None
+        else:
+            probs, _ = attention_fwd(TDesc(q, D, S * D), TDesc(k, D, S * D), TDesc(v, D, S * D),
+                                     TDesc(att, D, S * D), B, H, S, S, hd, 1.0 / math.sqrt(hd),
+                                     kmask=kmask, causal=True)
         h1 = ops.linear_fwd(att, wo, residual=x2)
         _, y2, rstd2 = ops.rmsnorm_fwd(h1, ln2, eps)
         g, u = ops.linear_fwd(y2, wg), ops.linear_fwd(y2, wu)
         a = ops.swiglu_fwd(g, u)
         out = ops.linear_fwd(a, wd, residual=h1)
-        ctx.save_for_backward(x2, rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, a, pos, cos,
-                              sin, wq, wk, wv, wo, wg, wu, wd, ln1, ln2)
-        ctx.dims = (B, S, D, H, hd)
+        if grad_mode:
+            ctx.save_for_backward(x2, rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, a, pos,
+                                  cos, sin, wq, wk, wv, wo, wg, wu, wd, ln1, ln2)
+            ctx.dims = (B, S, D, H, hd)
         return out.view(B, S, D)
 
     @staticmethod
@@ -232,10 +254,16 @@ class EncoderLayerFn(torch.autograd.Function):
         v = ops.linear_fwd(y1, wv, bias=bv)
         att = torch.empty((M, E), dtype=x.dtype, device=x.device)
         d = lambda t: TDesc(t, E, T * E)  # noqa: E731
-        probs, _ = attention_fwd(d(q), d(k), d(v), d(att), B, H, T, T, hd, hd ** -0.5)
+        grad_mode = any(ctx.needs_input_grad)
+        if not grad_mode and flash_ok(x.dtype, hd):
+            # frozen tower / inference: fused attention, the T x T scores never reach HBM
+            ops.flash_attn_fwd(q, k, v, att, B, H, T, T, hd, E, T * E, E, T * E, E, T * E, E, T * E,
+                               hd ** -0.5)
+            probs = None
+        else:
+            probs, _ = attention_fwd(d(q), d(k), d(v), d(att), B, H, T, T, hd, hd ** -0.5)
         h1 = ops.linear_fwd(att, wo, bias=bo, residual=x2)
         y2, mean2, rstd2 = ops.layernorm_fwd(h1, ln2w, ln2b, eps)
-        grad_mode = torch.is_grad_enabled() and any(ctx.needs_input_grad)
         if grad_mode:
             f1 = ops.linear_fwd(y2, w1, bias=b1)
             a = ops.act_fwd(f1, act)
@@ -434,15 +462,16 @@ def _align_fwd(feats, E, prm, heads, kw, stride, p, seed):
     Lq = B * Lout
     q = ops.linear_fwd(t, in_w[:D], bias=in_b[:D])
     Lk = V + 2
-    kv = torch.empty((Lk, 2 * D), dtype=feats.dtype, device=feats.device)
+    Lkp = _pad64(Lk)   # rows [V+1, Lkp) are zero: the add_zero_attn row + alignment padding
+    kv = torch.empty((Lkp, 2 * D), dtype=feats.dtype, device=feats.device)
     ops.gemm_raw(E, in_w, kv, V, 2 * D, D, D, D, 2 * D, bias=in_b[D:], bias_mode=1, b_off=D * D)
     ops.copy2d(bias_k, kv, 1, D, D, 2 * D, dst_off=V * 2 * D)
     ops.copy2d(bias_v, kv, 1, D, D, 2 * D, dst_off=V * 2 * D + D)
-    ops.fill_(kv[V + 1], 0.0)
+    ops.fill_(kv[V + 1:], 0.0)
     o = torch.empty((Lq, D), dtype=feats.dtype, device=feats.device)
     kd, vd = TDesc(kv, 2 * D, 0, 0), TDesc(kv, 2 * D, 0, D)
     probs, pd = attention_fwd(TDesc(q, D, 0), kd, vd, TDesc(o, D, 0), 1, H, Lq, Lk, hd,
-                              math.sqrt(1.0 / hd), p=p, seed=seed)
+                              math.sqrt(1.0 / hd), p=p, seed=seed, Lk_pad=Lkp)
     aligned = ops.linear_fwd(o, out_w, bias=out_b)  # rows are (b, j): [B, Lout, D]
     saved = (f2, cols, pj, t, q, kv, probs, pd, o)
     return aligned, Lout, saved
@@ -463,7 +492,7 @@ def _align_bwd(da, E, dE, dE_init, prm, saved, dims, need_feats):
     kd, vd = TDesc(kv, 2 * D, 0, 0), TDesc(kv, 2 * D, 0, D)
     attention_bwd(TDesc(do, D, 0), TDesc(q, D, 0), kd, vd, probs, pd, TDesc(dq, D, 0),
                   TDesc(dkv, 2 * D, 0, 0), TDesc(dkv, 2 * D, 0, D), 1, H, Lq, Lk, hd,
-                  math.sqrt(1.0 / hd), p=p, seed=seed)
+                  math.sqrt(1.0 / hd), p=p, seed=seed, Lk_pad=kv.shape[0])
     brow = torch.empty((1, 2 * D), dtype=da.dtype, device=da.device)
     ops.copy2d(dkv, brow, 1, 2 * D, 2 * D, 2 * D, src_off=V * 2 * D)
     g["bias_k"], g["bias_v"] = brow[0, :D].reshape(1, 1, D), brow[0, D:].reshape(1, 1, D)
@@ -666,7 +695,7 @@ class WhisperStemFn(torch.autograd.Function):
     def forward(ctx, mel, w1, b1, w2, b2, pos):
         B, Cm, Tm = mel.shape
         d = w1.shape[0]
-        grad_mode = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        grad_mode = any(ctx.needs_input_grad)
         mel = mel.contiguous()
         cols1, L1 = ops.im2col1d(mel, B, Cm, Tm, 3, 1, 1, Cm * Tm, Tm, 1)
         w1v = w1.view(d, Cm * 3)

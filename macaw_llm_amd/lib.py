@@ -81,6 +81,8 @@ SIGNATURES = {
     "mk_softmax_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i32, _f32, _u64, _i32,
                        _vp],
     "mk_softmax_bwd": [_vp, _vp, _i32, _i32, _i32, _i64, _f32, _f32, _u64, _i32, _vp],
+    "mk_flash_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64,
+                          _i64, _i64, _i64, _i64, _i64, _f32, _i32, _i32, _vp],
     "mk_cross_entropy": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp],
     "mk_cross_entropy_bwd": [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i64, _i32, _vp],
     "mk_adamw": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _i32,

@@ -380,6 +380,18 @@ def softmax_bwd_(probs, dprobs, nz, Lq, Lk, ld, scale=1.0, dropout_p=0.0, seed=0
     return dprobs
 
 
+def flash_attn_fwd(q, k, v, o, B, H, Lq, Lk, hd, q_ld, q_bs, k_ld, k_bs, v_ld, v_bs, o_ld, o_bs,
+                   scale, kmask=None, causal=False, lse=None, q_off=0, k_off=0, v_off=0, o_off=0):
+    """fused attention forward on strided bf16 buffers (element offsets/strides)"""
+    lib = _L.load()
+    es = q.element_size()
+    _L.check(lib.mk_flash_attn_fwd(_p(q) + q_off * es, _p(k) + k_off * es, _p(v) + v_off * es,
+                                   _p(o) + o_off * es, _p(lse), _p(kmask), B, H, Lq, Lk, hd, q_ld,
+                                   q_bs, k_ld, k_bs, v_ld, v_bs, o_ld, o_bs, float(scale),
+                                   int(causal), dt(q), _st()), "mk_flash_attn_fwd")
+    return o
+
+
 def cross_entropy(logits, labels, V):
     """logits [rows, ld>=V] row-major; labels int64 [rows] already shifted.
     returns (row_loss, row_lse, sum_cnt[2])"""

@@ -392,3 +392,39 @@ def test_adamw(dev, dtype):
         ops.adamw_(param, master, m, v, grad.to(dev), 3e-3, 0.9, 0.95, 1e-8, 0.1, step)
     torch.testing.assert_close(master.cpu(), p_ref.detach(), rtol=1e-5, atol=1e-6)
     assert torch.equal(param.cpu(), master.cpu().to(dtype))
+
+
+@pytest.mark.parametrize("hd", [64, 128])
+@pytest.mark.parametrize("Lq,Lk,causal,masked", [(144, 144, True, True), (257, 257, False, False),
+                                                 (70, 1500, False, False), (300, 300, True, False),
+                                                 (5, 5, True, False)])
+def test_flash_attention_fwd(dev, hd, Lq, Lk, causal, masked):
+    """fused attention == softmax(scale QK^T + mask) V in fp32 on the same bf16 inputs; bound =
+    bf16 rounding of P and of the output (rtol 8e-3 + 8e-3 abs at |o| <= ~1)."""
+    g = torch.Generator().manual_seed(Lq * 31 + Lk + hd)
+    Bn, H = 2, 3
+    D = H * hd
+    dtype = torch.bfloat16
+    q, k, v = (_rand((Bn * L, D), dtype, g) for L in (Lq, Lk, Lk))
+    kmask = torch.ones(Bn, Lk, dtype=torch.int32)
+    if masked:
+        kmask[1, -9:] = 0
+    o = torch.zeros((Bn * Lq, D), dtype=dtype, device=dev)
+    lse = torch.empty((Bn, H, Lq), dtype=torch.float32, device=dev)
+    scale = hd ** -0.5
+    ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), o, Bn, H, Lq, Lk, hd, D, Lq * D, D, Lk * D,
+                       D, Lk * D, D, Lq * D, scale, kmask=kmask.to(dev) if masked else None,
+                       causal=causal, lse=lse)
+    qf = q.float().view(Bn, Lq, H, hd).transpose(1, 2)
+    kf = k.float().view(Bn, Lk, H, hd).transpose(1, 2)
+    vf = v.float().view(Bn, Lk, H, hd).transpose(1, 2)
+    s = qf @ kf.transpose(-1, -2) * scale
+    if causal:
+        i = torch.arange(Lq)[:, None]
+        j = torch.arange(Lk)[None, :]
+        s = s.masked_fill(j > i + (Lk - Lq), float("-inf"))
+    if masked:
+        s = s.masked_fill(kmask[:, None, None, :] == 0, float("-inf"))
+    ref = (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(Bn * Lq, D)
+    _close(o, ref, dtype, what="flash fwd")
+    torch.testing.assert_close(lse.cpu(), torch.logsumexp(s, -1), rtol=1e-4, atol=1e-4)
