@@ -204,6 +204,15 @@ int mk_flash_attn_fwd(const void* q, const void* k, const void* v, void* o, floa
                       int64_t v_ld, int64_t v_bs, int64_t o_ld, int64_t o_bs, float scale,
                       int32_t causal, int32_t dtype, void* stream);
 
+/* Fused attention backward (recompute form): dq, dk, dv from q, k, v, o, do and the forward's
+ * lse; never stores P.  dq/dk/dv/do use the geometry of q/k/v/o.  dvec: f32 [B*H*Lq] scratch. */
+int mk_flash_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                      const float* lse, float* dvec, void* dq, void* dk, void* dv,
+                      const int32_t* kmask, int32_t B, int32_t H, int32_t Lq, int32_t Lk,
+                      int32_t hd, int64_t q_ld, int64_t q_bs, int64_t k_ld, int64_t k_bs,
+                      int64_t v_ld, int64_t v_bs, int64_t o_ld, int64_t o_bs, float scale,
+                      int32_t causal, int32_t dtype, void* stream);
+
 /* Shifted cross-entropy (modeling.py:600-610). The caller passes labels already shifted
  * (row r predicts labels[r]; -100 = ignore).  row_loss[r] = lse_r - logit[r][label] (0 when
  * ignored), row_lse[r] kept for backward, loss_sum_cnt = {sum of row losses, number of valid

@@ -37,14 +37,15 @@ MK_DEV int v_off(int key, int chunk) {  // V tile [64][HD] bf16, read through tr
 }
 
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void flash_fwd_kernel(FlashArgs a) {
+__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs a) {
   constexpr int KT = 64;                 // keys per LDS tile
   constexpr int NKD = HD / 16;           // MFMA k-steps over d for Q K^T
   constexpr int NDB = HD / 32;           // 32-wide d blocks of the output
   constexpr int CPR = HD / 8;            // 16-B chunks per row
-  __shared__ __attribute__((aligned(16))) char lds[2 * KT * HD * 2];
+  __shared__ __attribute__((aligned(16))) char lds[2 * KT * HD * 2 + KT * 4];
   char* ldsK = lds;
   char* ldsV = lds + KT * HD * 2;
+  int* ldsM = reinterpret_cast<int*>(lds + 2 * KT * HD * 2);   // key validity of the tile
   const int b = blockIdx.z, h = blockIdx.y;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int half = l >> 5, lq = l & 31;
@@ -95,6 +96,10 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashArgs a) {
       *reinterpret_cast<uint4*>(ldsK + k_off<HD>(row, ch)) = kv4;
       *reinterpret_cast<uint4*>(ldsV + v_off<HD>(row, ch)) = vv4;
     }
+    if (threadIdx.x < KT) {
+      const int kg = kbase + threadIdx.x;
+      ldsM[threadIdx.x] = (kg < a.Lk) && (!km || km[kg] != 0);
+    }
     __syncthreads();
     if (q0 >= a.Lq) continue;            // wave has no rows (still takes part in the barriers)
 
@@ -111,12 +116,17 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashArgs a) {
       }
       // ---- mask + online softmax (this lane: query qg, keys key(r)) ----
       float mx = -INFINITY;
+      int mk[16];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int4 m4 = *reinterpret_cast<const int4*>(ldsM + sb * 32 + 8 * g4 + 4 * half);
+        mk[4 * g4] = m4.x; mk[4 * g4 + 1] = m4.y; mk[4 * g4 + 2] = m4.z; mk[4 * g4 + 3] = m4.w;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kg = kbase + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        bool ok = kg < a.Lk;
+        bool ok = mk[r] != 0;
         if (CAUSAL) ok = ok && (kg <= qg + shift);
-        if (km) ok = ok && (km[kg < a.Lk ? kg : 0] != 0);
         s[r] = ok ? s[r] * a.scale : -INFINITY;
         mx = fmaxf(mx, s[r]);
       }
@@ -207,5 +217,330 @@ extern "C" int mk_flash_attn_fwd(const void* q, const void* k, const void* v, vo
     if (causal) MK_LAUNCH((flash_fwd_kernel<64, true>), grid, block, 0, st, a);
     else MK_LAUNCH((flash_fwd_kernel<64, false>), grid, block, 0, st, a);
   }
+  return mk_check_launch();
+}
+
+// =====================================================================================
+// Fused attention BACKWARD (recompute form): given q, k, v, o, do and the forward's
+// log-sum-exp, produce dq, dk, dv without ever storing P.  Three kernels:
+//   flash_bwd_prep : Dv[b,h,q] = sum_d do[q,d] * o[q,d]                       (HBM-bound)
+//   flash_bwd_dq   : block = 128 queries, walks the key tiles  (lane <-> query, as forward)
+//   flash_bwd_dkv  : block = 128 keys,    walks the query tiles (lane <-> key)
+// In both MFMA kernels every product is arranged so that the softmax-shaped tile (P, dS) is
+// consumed as the B operand straight out of the accumulator registers that produced it:
+//   dq kernel : S^T = K Q^T, dP^T = V dO^T  -> dS^T (lane = query)  -> dQ^T += K^T dS^T
+//   dkv kernel: S   = Q K^T, dP   = dO V^T  -> P, dS (lane = key)   -> dV^T += dO^T P,
+//                                                                     dK^T += Q^T dS
+// with the transposed operands (K^T, dO^T, Q^T) read from row-major LDS tiles through
+// ds_read_b64_tr_b16 using the same k-slot <-> row mapping as the accumulator layout.
+// =====================================================================================
+namespace {
+
+struct FlashBwdArgs {
+  const bf16* q; const bf16* k; const bf16* v; const bf16* o; const bf16* dout;
+  bf16* dq; bf16* dk; bf16* dv;
+  const float* lse; float* dvec; const int32_t* kmask;
+  int B, H, Lq, Lk;
+  long q_ld, q_bs, k_ld, k_bs, v_ld, v_bs, o_ld, o_bs;  // dq/dk/dv/do share q/k/v/o geometry
+  float scale;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void flash_bwd_prep_kernel(FlashBwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, h, q) flattened
+  const long total = (long)a.B * a.H * a.Lq;
+  if (row >= total) return;
+  const int qi = (int)(row % a.Lq);
+  const long bh = row / a.Lq;
+  const int h = (int)(bh % a.H);
+  const long b = bh / a.H;
+  const bf16* O = a.o + b * a.o_bs + (long)qi * a.o_ld + (long)h * HD;
+  const bf16* dO = a.dout + b * a.o_bs + (long)qi * a.o_ld + (long)h * HD;
+  float s = 0.f;
+  for (int d = lane; d < HD; d += 64) s += (float)O[d] * (float)dO[d];
+  s = wave_sum(s);
+  if (lane == 0) a.dvec[row] = s;
+}
+
+// tile stored twice: [rows][HD] with the b128 swizzle (k_off) and with the tr swizzle (v_off)
+template <int HD, int ROWS>
+MK_DEV void stage_rows(const bf16* src, long ld, int row0, int nrows_valid, char* lds_b128,
+                       char* lds_tr) {
+  constexpr int CPR = HD / 8;
+#pragma unroll
+  for (int i = 0; i < (ROWS * CPR) / 256; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    const int row = c / CPR, ch = c % CPR;
+    uint4 v4 = make_uint4(0, 0, 0, 0);
+    if (row0 + row < nrows_valid) v4 = *reinterpret_cast<const uint4*>(src + (long)(row0 + row) * ld + ch * 8);
+    if (lds_b128) *reinterpret_cast<uint4*>(lds_b128 + k_off<HD>(row, ch)) = v4;
+    if (lds_tr) *reinterpret_cast<uint4*>(lds_tr + v_off<HD>(row, ch)) = v4;
+  }
+}
+
+// A-operand fragment X^T[d-block rows][k-slots <-> rows r0 + kappa] from a row-major LDS tile
+template <int HD>
+MK_DEV bf16x8 tr_frag(const char* lds_tr, int rowbase16, int dblk) {
+  const int l = threadIdx.x & 63, li = l & 15, half = l >> 5;
+  const int col = dblk * 32 + 16 * ((l >> 4) & 1) + 4 * (li & 3);
+  bf16x8 f;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int row = rowbase16 + 8 * r + 4 * half + (li >> 2);
+    const int off = v_off<HD>(row, col >> 3) + ((col & 7) << 1);
+    const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (__attribute__((address_space(3))) bf16x4*)(lds_tr + off));
+    f[4 * r] = t[0]; f[4 * r + 1] = t[1]; f[4 * r + 2] = t[2]; f[4 * r + 3] = t[3];
+  }
+  return f;
+}
+
+// ------------------------------------------------------------------ dQ kernel --
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(FlashBwdArgs a) {
+  constexpr int KT = 64, NKD = HD / 16, NDB = HD / 32;
+  __shared__ __attribute__((aligned(16))) char lds[3 * KT * HD * 2 + KT * 4];
+  int* ldsM = reinterpret_cast<int*>(lds + 3 * KT * HD * 2);
+  char* ldsK = lds;                      // K tile, b128 image (A operand of S^T = K Q^T)
+  char* ldsKt = lds + KT * HD * 2;       // K tile, tr image   (K^T for dQ^T += K^T dS^T)
+  char* ldsV = lds + 2 * KT * HD * 2;    // V tile, b128 image (A operand of dP^T = V dO^T)
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int half = l >> 5, lq = l & 31;
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const int qg = q0 + lq;
+  const bf16* Q = a.q + (long)b * a.q_bs + (long)h * HD;
+  const bf16* dO = a.dout + (long)b * a.o_bs + (long)h * HD;
+  const bf16* K = a.k + (long)b * a.k_bs + (long)h * HD;
+  const bf16* V = a.v + (long)b * a.v_bs + (long)h * HD;
+  const int32_t* km = a.kmask ? a.kmask + (long)b * a.Lk : nullptr;
+  bf16x8 qf[NKD], dof[NKD];
+#pragma unroll
+  for (int kd = 0; kd < NKD; ++kd) {
+    if (qg < a.Lq) {
+      qf[kd] = *reinterpret_cast<const bf16x8*>(Q + (long)qg * a.q_ld + 16 * kd + 8 * half);
+      dof[kd] = *reinterpret_cast<const bf16x8*>(dO + (long)qg * a.o_ld + 16 * kd + 8 * half);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { qf[kd][e] = (bf16)0.f; dof[kd][e] = (bf16)0.f; }
+    }
+  }
+  const long rowid = ((long)b * a.H + h) * a.Lq + min(qg, a.Lq - 1);
+  const float lse = a.lse[rowid], dv_ = a.dvec[rowid];
+  f32x16 acc[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+  const int shift = a.Lk - a.Lq;
+  int k_end = a.Lk;
+  if (CAUSAL) k_end = min(a.Lk, blockIdx.x * 128 + 128 + shift);
+  const int ntiles = (k_end + KT - 1) / KT;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int kbase = kt * KT;
+    __syncthreads();
+    stage_rows<HD, KT>(K, a.k_ld, kbase, a.Lk, ldsK, ldsKt);
+    stage_rows<HD, KT>(V, a.v_ld, kbase, a.Lk, ldsV, nullptr);
+    if (threadIdx.x < KT) {
+      const int kg = kbase + threadIdx.x;
+      ldsM[threadIdx.x] = (kg < a.Lk) && (!km || km[kg] != 0);
+    }
+    __syncthreads();
+    if (q0 >= a.Lq) continue;
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+      for (int kd = 0; kd < NKD; ++kd) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ldsK + k_off<HD>(sb * 32 + lq, 2 * kd + half));
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(ldsV + k_off<HD>(sb * 32 + lq, 2 * kd + half));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kd], dp, 0, 0, 0);
+      }
+      bf16x8 dsf[2];
+      int mk[16];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int4 m4 = *reinterpret_cast<const int4*>(ldsM + sb * 32 + 8 * g4 + 4 * half);
+        mk[4 * g4] = m4.x; mk[4 * g4 + 1] = m4.y; mk[4 * g4 + 2] = m4.z; mk[4 * g4 + 3] = m4.w;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kg = kbase + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        bool ok = mk[r] != 0;
+        if (CAUSAL) ok = ok && (kg <= qg + shift);
+        const float p = ok ? __expf(s[r] * a.scale - lse) : 0.f;
+        const float ds = p * (dp[r] - dv_) * a.scale;
+        dsf[r >> 3][r & 7] = (bf16)ds;
+      }
+#pragma unroll
+      for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              tr_frag<HD>(ldsKt, sb * 32 + ks * 16, d), dsf[ks], acc[d], 0, 0, 0);
+    }
+  }
+  if (qg >= a.Lq) return;
+  bf16* DQ = a.dq + (long)b * a.q_bs + (long)qg * a.q_ld + (long)h * HD;
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      bf16x4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = (bf16)acc[d][4 * q4 + e];
+      *reinterpret_cast<bf16x4*>(DQ + d * 32 + 8 * q4 + 4 * half) = ov;
+    }
+}
+
+// ---------------------------------------------------------------- dK/dV kernel --
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashBwdArgs a) {
+  constexpr int QT = 64, NKD = HD / 16, NDB = HD / 32;
+  __shared__ __attribute__((aligned(16))) char lds[4 * QT * HD * 2 + 2 * QT * 4];
+  char* ldsQ = lds;                      // Q tile b128 image  (A operand of S  = Q K^T)
+  char* ldsQt = lds + QT * HD * 2;       // Q tile tr image    (Q^T for dK^T += Q^T dS)
+  char* ldsD = lds + 2 * QT * HD * 2;    // dO tile b128 image (A operand of dP = dO V^T)
+  char* ldsDt = lds + 3 * QT * HD * 2;   // dO tile tr image   (dO^T for dV^T += dO^T P)
+  float* ldsLse = reinterpret_cast<float*>(lds + 4 * QT * HD * 2);
+  float* ldsDv = ldsLse + QT;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int half = l >> 5, lk = l & 31;
+  const int k0 = blockIdx.x * 128 + w * 32;
+  const int kg = k0 + lk;                // this lane's key
+  const bf16* Q = a.q + (long)b * a.q_bs + (long)h * HD;
+  const bf16* dO = a.dout + (long)b * a.o_bs + (long)h * HD;
+  const bf16* K = a.k + (long)b * a.k_bs + (long)h * HD;
+  const bf16* V = a.v + (long)b * a.v_bs + (long)h * HD;
+  const int32_t* km = a.kmask ? a.kmask + (long)b * a.Lk : nullptr;
+  bf16x8 kf[NKD], vf[NKD];               // B operands: lane holds K/V[kg][16*kd + 8*half .. +8]
+#pragma unroll
+  for (int kd = 0; kd < NKD; ++kd) {
+    if (kg < a.Lk) {
+      kf[kd] = *reinterpret_cast<const bf16x8*>(K + (long)kg * a.k_ld + 16 * kd + 8 * half);
+      vf[kd] = *reinterpret_cast<const bf16x8*>(V + (long)kg * a.v_ld + 16 * kd + 8 * half);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { kf[kd][e] = (bf16)0.f; vf[kd][e] = (bf16)0.f; }
+    }
+  }
+  const bool key_ok = (kg < a.Lk) && (!km || km[kg < a.Lk ? kg : 0] != 0);
+  f32x16 dka[NDB], dva[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dka[d][e] = 0.f; dva[d][e] = 0.f; }
+  const int shift = a.Lk - a.Lq;
+  // queries that can see this block's keys: q >= key - shift
+  int q_begin = 0;
+  if (CAUSAL) q_begin = max(0, blockIdx.x * 128 - shift) / QT * QT;
+  const long rowbase = ((long)b * a.H + h) * a.Lq;
+  for (int qt = q_begin; qt < a.Lq; qt += QT) {
+    __syncthreads();
+    stage_rows<HD, QT>(Q, a.q_ld, qt, a.Lq, ldsQ, ldsQt);
+    stage_rows<HD, QT>(dO, a.o_ld, qt, a.Lq, ldsD, ldsDt);
+    if (threadIdx.x < QT) {
+      const int qi = qt + threadIdx.x;
+      ldsLse[threadIdx.x] = qi < a.Lq ? a.lse[rowbase + qi] : 0.f;
+      ldsDv[threadIdx.x] = qi < a.Lq ? a.dvec[rowbase + qi] : 0.f;
+    }
+    __syncthreads();
+    if (k0 >= a.Lk) continue;
+#pragma unroll 1
+    for (int sb = 0; sb < 2; ++sb) {
+      // S = Q K^T and dP = dO V^T for 32 queries x 32 keys: D[i = q][j = key]
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+      for (int kd = 0; kd < NKD; ++kd) {
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(ldsQ + k_off<HD>(sb * 32 + lk, 2 * kd + half));
+        const bf16x8 da = *reinterpret_cast<const bf16x8*>(ldsD + k_off<HD>(sb * 32 + lk, 2 * kd + half));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kd], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kd], dp, 0, 0, 0);
+      }
+      bf16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // query row inside the tile
+        const int qi = qt + ql;
+        bool ok = key_ok && (qi < a.Lq);
+        if (CAUSAL) ok = ok && (kg <= qi + shift);
+        const float p = ok ? __expf(s[r] * a.scale - ldsLse[ql]) : 0.f;
+        const float ds = p * (dp[r] - ldsDv[ql]) * a.scale;
+        pf[r >> 3][r & 7] = (bf16)p;
+        dsf[r >> 3][r & 7] = (bf16)ds;
+      }
+#pragma unroll
+      for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          dva[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              tr_frag<HD>(ldsDt, sb * 32 + ks * 16, d), pf[ks], dva[d], 0, 0, 0);
+          dka[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              tr_frag<HD>(ldsQt, sb * 32 + ks * 16, d), dsf[ks], dka[d], 0, 0, 0);
+        }
+    }
+  }
+  if (kg >= a.Lk) return;
+  bf16* DK = a.dk + (long)b * a.k_bs + (long)kg * a.k_ld + (long)h * HD;
+  bf16* DV = a.dv + (long)b * a.v_bs + (long)kg * a.v_ld + (long)h * HD;
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      bf16x4 ok_, ov_;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ok_[e] = (bf16)dka[d][4 * q4 + e]; ov_[e] = (bf16)dva[d][4 * q4 + e]; }
+      *reinterpret_cast<bf16x4*>(DK + d * 32 + 8 * q4 + 4 * half) = ok_;
+      *reinterpret_cast<bf16x4*>(DV + d * 32 + 8 * q4 + 4 * half) = ov_;
+    }
+}
+
+}  // namespace
+
+extern "C" int mk_flash_attn_bwd(const void* q, const void* k, const void* v, const void* o,
+                                 const void* dout, const float* lse, float* dvec, void* dq,
+                                 void* dk, void* dv, const int32_t* kmask, int32_t B, int32_t H,
+                                 int32_t Lq, int32_t Lk, int32_t hd, int64_t q_ld, int64_t q_bs,
+                                 int64_t k_ld, int64_t k_bs, int64_t v_ld, int64_t v_bs,
+                                 int64_t o_ld, int64_t o_bs, float scale, int32_t causal,
+                                 int32_t dtype, void* stream) {
+  if (!q || !k || !v || !o || !dout || !lse || !dvec || !dq || !dk || !dv || B <= 0 || H <= 0 ||
+      Lq <= 0 || Lk <= 0)
+    return MK_ERR_BAD_ARG;
+  if (dtype != MK_BF16 || (hd != 64 && hd != 128)) return MK_ERR_UNSUPPORTED;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
+                       reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(o) |
+                       reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dq) |
+                       reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv);
+  if ((al & 15) || (q_ld % 8) || (k_ld % 8) || (v_ld % 8) || (o_ld % 8) || (q_bs % 8) ||
+      (k_bs % 8) || (v_bs % 8) || (o_bs % 8))
+    return MK_ERR_UNSUPPORTED;
+  FlashBwdArgs a;
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (const bf16*)o;
+  a.dout = (const bf16*)dout; a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv;
+  a.lse = lse; a.dvec = dvec; a.kmask = kmask;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
+  a.q_ld = q_ld; a.q_bs = q_bs; a.k_ld = k_ld; a.k_bs = k_bs; a.v_ld = v_ld; a.v_bs = v_bs;
+  a.o_ld = o_ld; a.o_bs = o_bs;
+  a.scale = scale;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long rows = (long)B * H * Lq;
+  dim3 gq(mk_cdiv(Lq, 128), H, B), gk(mk_cdiv(Lk, 128), H, B), block(256);
+#define MK_FB(HDV, CZ)                                                                         \
+  do {                                                                                         \
+    MK_LAUNCH((flash_bwd_prep_kernel<HDV>), dim3((unsigned)((rows + 3) / 4)), block, 0, st, a); \
+    MK_LAUNCH((flash_bwd_dq_kernel<HDV, CZ>), gq, block, 0, st, a);                            \
+    MK_LAUNCH((flash_bwd_dkv_kernel<HDV, CZ>), gk, block, 0, st, a);                           \
+  } while (0)
+  if (hd == 128) { if (causal) MK_FB(128, true); else MK_FB(128, false); }
+  else { if (causal) MK_FB(64, true); else MK_FB(64, false); }
+#undef MK_FB
   return mk_check_launch();
 }

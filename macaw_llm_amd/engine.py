@@ -116,10 +116,14 @@ class LlamaLayerFn(torch.autograd.Function):
         ops.rope_(k, cos, sin, pos, H, hd)
         att = torch.empty((M, D), dtype=x.dtype, device=x.device)
         grad_mode = any(ctx.needs_input_grad)
-        if not grad_mode and flash_ok(x.dtype, hd):
+        use_flash = flash_ok(x.dtype, hd)
+        if use_flash:
+            # fused attention: the S x S scores never reach HBM; training keeps only the
+            # per-row log-sum-exp and recomputes P in the fused backward
+            lse = torch.empty((B, H, S), dtype=torch.float32, device=x.device) if grad_mode else None
             ops.flash_attn_fwd(q, k, v, att, B, H, S, S, hd, D, S * D, D, S * D, D, S * D, D, S * D,
-                               1.0 / math.sqrt(hd), kmask=kmask, causal=True)
-            probs = None
+                               1.0 / math.sqrt(hd), kmask=kmask, causal=True, lse=lse)
+            probs = lse
         else:
             probs, _ = attention_fwd(TDesc(q, D, S * D), TDesc(k, D, S * D), TDesc(v, D, S * D),
                                      TDesc(att, D, S * D), B, H, S, S, hd, 1.0 / math.sqrt(hd),
@@ -131,15 +135,15 @@ class LlamaLayerFn(torch.autograd.Function):
         out = ops.linear_fwd(a, wd, residual=h1)
         if grad_mode:
             ctx.save_for_backward(x2, rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, a, pos,
-                                  cos, sin, wq, wk, wv, wo, wg, wu, wd, ln1, ln2)
-            ctx.dims = (B, S, D, H, hd)
+                                  cos, sin, wq, wk, wv, wo, wg, wu, wd, ln1, ln2, kmask)
+            ctx.dims = (B, S, D, H, hd, use_flash)
         return out.view(B, S, D)
 
     @staticmethod
     def backward(ctx, dout):
         (x2, rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, a, pos, cos, sin, wq, wk, wv, wo,
-         wg, wu, wd, ln1, ln2) = ctx.saved_tensors
-        B, S, D, H, hd = ctx.dims
+         wg, wu, wd, ln1, ln2, kmask) = ctx.saved_tensors
+        B, S, D, H, hd, use_flash = ctx.dims
         M = B * S
         need = ctx.needs_input_grad
         dout2 = _c2(dout, M, D)
@@ -159,8 +163,13 @@ class LlamaLayerFn(torch.autograd.Function):
         dwo = ops.linear_dw(dh1, att) if need[10] else None
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         d = lambda t: TDesc(t, D, S * D)  # noqa: E731
-        attention_bwd(d(datt), d(q), d(k), d(v), probs, None, d(dq), d(dk), d(dv), B, H, S, S, hd,
-                      1.0 / math.sqrt(hd))
+        if use_flash:
+            ops.flash_attn_bwd(q, k, v, att, datt, probs, dq, dk, dv, B, H, S, S, hd, D, S * D, D,
+                               S * D, D, S * D, D, S * D, 1.0 / math.sqrt(hd), kmask=kmask,
+                               causal=True)
+        else:
+            attention_bwd(d(datt), d(q), d(k), d(v), probs, None, d(dq), d(dk), d(dv), B, H, S, S,
+                          hd, 1.0 / math.sqrt(hd))
         ops.rope_(dq, cos, sin, pos, H, hd, inverse=True)
         ops.rope_(dk, cos, sin, pos, H, hd, inverse=True)
         dy1 = ops.linear_dx(dq, wq)
@@ -255,11 +264,12 @@ class EncoderLayerFn(torch.autograd.Function):
         att = torch.empty((M, E), dtype=x.dtype, device=x.device)
         d = lambda t: TDesc(t, E, T * E)  # noqa: E731
         grad_mode = any(ctx.needs_input_grad)
-        if not grad_mode and flash_ok(x.dtype, hd):
-            # frozen tower / inference: fused attention, the T x T scores never reach HBM
+        use_flash = flash_ok(x.dtype, hd)
+        if use_flash:   # fused attention, the T x T scores never reach HBM
+            lse = torch.empty((B, H, T), dtype=torch.float32, device=x.device) if grad_mode else None
             ops.flash_attn_fwd(q, k, v, att, B, H, T, T, hd, E, T * E, E, T * E, E, T * E, E, T * E,
-                               hd ** -0.5)
-            probs = None
+                               hd ** -0.5, lse=lse)
+            probs = lse
         else:
             probs, _ = attention_fwd(d(q), d(k), d(v), d(att), B, H, T, T, hd, hd ** -0.5)
         h1 = ops.linear_fwd(att, wo, bias=bo, residual=x2)
@@ -274,14 +284,14 @@ class EncoderLayerFn(torch.autograd.Function):
         if grad_mode:
             ctx.save_for_backward(x2, mean1, rstd1, y1, q, k, v, probs, att, h1, mean2, rstd2, y2,
                                   f1, a, ln1w, wq, wk, wv, wo, ln2w, w1, w2)
-            ctx.dims = (B, T, E, H, hd, act, bk is not None)
+            ctx.dims = (B, T, E, H, hd, act, bk is not None, use_flash)
         return out.view(B, T, E)
 
     @staticmethod
     def backward(ctx, dout):
         (x2, mean1, rstd1, y1, q, k, v, probs, att, h1, mean2, rstd2, y2, f1, a, ln1w, wq, wk, wv,
          wo, ln2w, w1, w2) = ctx.saved_tensors
-        B, T, E, H, hd, act, has_bk = ctx.dims
+        B, T, E, H, hd, act, has_bk, use_flash = ctx.dims
         M = B * T
         dout2 = _c2(dout, M, E)
         da = ops.linear_dx(dout2, w2)
@@ -294,8 +304,12 @@ class EncoderLayerFn(torch.autograd.Function):
         dwo, dbo = ops.linear_dw(dh1, att), ops.colsum(dh1)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         d = lambda t: TDesc(t, E, T * E)  # noqa: E731
-        attention_bwd(d(datt), d(q), d(k), d(v), probs, None, d(dq), d(dk), d(dv), B, H, T, T, hd,
-                      hd ** -0.5)
+        if use_flash:
+            ops.flash_attn_bwd(q, k, v, att, datt, probs, dq, dk, dv, B, H, T, T, hd, E, T * E, E,
+                               T * E, E, T * E, E, T * E, hd ** -0.5)
+        else:
+            attention_bwd(d(datt), d(q), d(k), d(v), probs, None, d(dq), d(dk), d(dv), B, H, T, T,
+                          hd, hd ** -0.5)
         dy1 = ops.linear_dx(dq, wq)
         ops.linear_dx(dk, wk, out=dy1, accumulate=True)
         ops.linear_dx(dv, wv, out=dy1, accumulate=True)

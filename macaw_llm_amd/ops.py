@@ -392,6 +392,16 @@ def flash_attn_fwd(q, k, v, o, B, H, Lq, Lk, hd, q_ld, q_bs, k_ld, k_bs, v_ld, v
     return o
 
 
+def flash_attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, B, H, Lq, Lk, hd, q_ld, q_bs, k_ld, k_bs, v_ld,
+                   v_bs, o_ld, o_bs, scale, kmask=None, causal=False):
+    lib = _L.load()
+    dvec = torch.empty(B * H * Lq, dtype=torch.float32, device=q.device)
+    _L.check(lib.mk_flash_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(dvec), _p(dq),
+                                   _p(dk), _p(dv), _p(kmask), B, H, Lq, Lk, hd, q_ld, q_bs, k_ld,
+                                   k_bs, v_ld, v_bs, o_ld, o_bs, float(scale), int(causal), dt(q),
+                                   _st()), "mk_flash_attn_bwd")
+
+
 def cross_entropy(logits, labels, V):
     """logits [rows, ld>=V] row-major; labels int64 [rows] already shifted.
     returns (row_loss, row_lse, sum_cnt[2])"""

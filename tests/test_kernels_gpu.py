@@ -428,3 +428,47 @@ def test_flash_attention_fwd(dev, hd, Lq, Lk, causal, masked):
     ref = (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(Bn * Lq, D)
     _close(o, ref, dtype, what="flash fwd")
     torch.testing.assert_close(lse.cpu(), torch.logsumexp(s, -1), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("hd", [64, 128])
+@pytest.mark.parametrize("Lq,Lk,causal,masked", [(144, 144, True, True), (257, 257, False, False),
+                                                 (130, 300, False, True), (300, 300, True, False)])
+def test_flash_attention_bwd(dev, hd, Lq, Lk, causal, masked):
+    """fused backward (recompute) == autograd of softmax(scale QK^T + mask) V in fp32 on the same
+    bf16 inputs.  bf16 P / dS operands => rtol 2e-2 of the gradient scale."""
+    g = torch.Generator().manual_seed(Lq * 17 + Lk + hd)
+    Bn, H = 2, 2
+    D = H * hd
+    dtype = torch.bfloat16
+    q, k, v = (_rand((Bn * L, D), dtype, g, 0.7) for L in (Lq, Lk, Lk))
+    do = _rand((Bn * Lq, D), dtype, g)
+    kmask = torch.ones(Bn, Lk, dtype=torch.int32)
+    if masked:
+        kmask[1, -11:] = 0
+    km_d = kmask.to(dev) if masked else None
+    scale = hd ** -0.5
+    qd, kd_, vd, dod = q.to(dev), k.to(dev), v.to(dev), do.to(dev)
+    o = torch.zeros((Bn * Lq, D), dtype=dtype, device=dev)
+    lse = torch.empty((Bn, H, Lq), dtype=torch.float32, device=dev)
+    geo = (D, Lq * D, D, Lk * D, D, Lk * D, D, Lq * D)
+    ops.flash_attn_fwd(qd, kd_, vd, o, Bn, H, Lq, Lk, hd, *geo, scale, kmask=km_d, causal=causal, lse=lse)
+    dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd_), torch.zeros_like(vd)
+    ops.flash_attn_bwd(qd, kd_, vd, o, dod, lse, dq, dk, dv, Bn, H, Lq, Lk, hd, *geo, scale,
+                       kmask=km_d, causal=causal)
+    qf = q.float().view(Bn, Lq, H, hd).transpose(1, 2).requires_grad_(True)
+    kf = k.float().view(Bn, Lk, H, hd).transpose(1, 2).requires_grad_(True)
+    vf = v.float().view(Bn, Lk, H, hd).transpose(1, 2).requires_grad_(True)
+    s = qf @ kf.transpose(-1, -2) * scale
+    if causal:
+        i = torch.arange(Lq)[:, None]
+        j = torch.arange(Lk)[None, :]
+        s = s.masked_fill(j > i + (Lk - Lq), float("-inf"))
+    if masked:
+        s = s.masked_fill(kmask[:, None, None, :] == 0, float("-inf"))
+    out = torch.softmax(s, -1) @ vf
+    out.backward(do.float().view(Bn, Lq, H, hd).transpose(1, 2))
+    for name, got, ref, L in (("dq", dq, qf.grad, Lq), ("dk", dk, kf.grad, Lk), ("dv", dv, vf.grad, Lk)):
+        ref2 = ref.transpose(1, 2).reshape(Bn * L, D)
+        err = (got.float().cpu() - ref2).abs().max().item()
+        lim = 2e-2 * ref2.abs().max().item() + 2e-3
+        assert torch.isfinite(got).all() and err <= lim, (name, err, lim)
