@@ -125,6 +125,11 @@ int mk_rope(void* x, const void* cos_t, const void* sin_t, const int32_t* pos, i
 int mk_swiglu_fwd(const void* g, const void* u, void* a, int64_t n, int32_t dtype, void* stream);
 int mk_swiglu_bwd(const void* g, const void* u, const void* da, void* dg, void* du, int64_t n,
                   int32_t dtype, void* stream);
+/* pitched 2-D forms for the fused gate|up projection buffer [rows, 2*cols] */
+int mk_swiglu2d_fwd(const void* g, const void* u, void* a, int64_t rows, int32_t cols,
+                    int64_t ld_in, int64_t ld_out, int32_t dtype, void* stream);
+int mk_swiglu2d_bwd(const void* g, const void* u, const void* da, void* dg, void* du, int64_t rows,
+                    int32_t cols, int64_t ld_gu, int64_t ld_a, int32_t dtype, void* stream);
 /* y = act(x): act 1 gelu(erf) (Whisper), 2 quick_gelu (CLIP). */
 int mk_act_fwd(const void* x, void* y, int64_t n, int32_t act, int32_t dtype, void* stream);
 /* activation backward: dx = dy * act'(x_pre); act 1 gelu(erf), 2 quick_gelu. x_pre is the

@@ -98,6 +98,47 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* g, const T* u,
   }
 }
 
+// 2-D (pitched) forms: g = gu[:, :cols], u = gu[:, cols:] inside one [rows, 2*cols] buffer
+// produced by the fused gate|up projection.
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu2d_fwd_kernel(const T* g, const T* u, T* a, long rows,
+                                                           int cols, long ld_in, long ld_out) {
+  constexpr int N = VecIO<T>::N;
+  const int cpr = cols / N;
+  const long total = rows * cpr;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / cpr;
+    const int c = (int)(i - r * cpr) * N;
+    float gv[N], uv[N], o[N];
+    VecIO<T>::load(g + r * ld_in + c, gv); VecIO<T>::load(u + r * ld_in + c, uv);
+#pragma unroll
+    for (int k = 0; k < N; ++k) o[k] = rnd<T>(gv[k] / (1.f + __expf(-gv[k]))) * uv[k];
+    VecIO<T>::store(a + r * ld_out + c, o);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu2d_bwd_kernel(const T* g, const T* u, const T* da,
+                                                           T* dg, T* du, long rows, int cols,
+                                                           long ld_gu, long ld_a) {
+  constexpr int N = VecIO<T>::N;
+  const int cpr = cols / N;
+  const long total = rows * cpr;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / cpr;
+    const int c = (int)(i - r * cpr) * N;
+    float gv[N], uv[N], dv[N], og[N], ou[N];
+    VecIO<T>::load(g + r * ld_gu + c, gv); VecIO<T>::load(u + r * ld_gu + c, uv);
+    VecIO<T>::load(da + r * ld_a + c, dv);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float sg = 1.f / (1.f + __expf(-gv[k]));
+      ou[k] = dv[k] * gv[k] * sg;
+      og[k] = dv[k] * uv[k] * sg * (1.f + gv[k] * (1.f - sg));
+    }
+    VecIO<T>::store(dg + r * ld_gu + c, og); VecIO<T>::store(du + r * ld_gu + c, ou);
+  }
+}
+
 // ------------------------------------------------------------ activations --
 MK_DEV float act_fwd(float v, int act) {
   if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
@@ -507,5 +548,25 @@ extern "C" int mk_copy2d(const void* src, void* dst, int32_t rows, int32_t cols,
     MK_LAUNCH((copy2d_kernel<4>), grid, block, 0, MK_ST, (const char*)src, (char*)dst, rows,
                        row_bytes, (long)ld_src * es, (long)ld_dst * es, (long)s_src * es,
                        (long)s_dst * es, vec);
+  return mk_check_launch();
+}
+
+extern "C" int mk_swiglu2d_fwd(const void* g, const void* u, void* a, int64_t rows, int32_t cols,
+                               int64_t ld_in, int64_t ld_out, int32_t dtype, void* stream) {
+  if (!g || !u || !a || rows <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
+  if (cols % 8 || ld_in % 8 || ld_out % 8) return MK_ERR_UNSUPPORTED;
+  MK_DISPATCH_T(dtype, MK_LAUNCH((swiglu2d_fwd_kernel<T>), dim3(ew_grid(rows * (cols / VecIO<T>::N))),
+                                 dim3(256), 0, MK_ST, (const T*)g, (const T*)u, (T*)a, (long)rows,
+                                 cols, (long)ld_in, (long)ld_out));
+  return mk_check_launch();
+}
+extern "C" int mk_swiglu2d_bwd(const void* g, const void* u, const void* da, void* dg, void* du,
+                               int64_t rows, int32_t cols, int64_t ld_gu, int64_t ld_a,
+                               int32_t dtype, void* stream) {
+  if (!g || !u || !da || !dg || !du || rows <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
+  if (cols % 8 || ld_gu % 8 || ld_a % 8) return MK_ERR_UNSUPPORTED;
+  MK_DISPATCH_T(dtype, MK_LAUNCH((swiglu2d_bwd_kernel<T>), dim3(ew_grid(rows * (cols / VecIO<T>::N))),
+                                 dim3(256), 0, MK_ST, (const T*)g, (const T*)u, (const T*)da, (T*)dg,
+                                 (T*)du, (long)rows, cols, (long)ld_gu, (long)ld_a));
   return mk_check_launch();
 }

@@ -61,12 +61,11 @@ MK_DEV int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
-MK_DEV void tile_from_index(int wg, int tiles_m, int tiles_n, int& tm, int& tn);
+MK_DEV void tile_from_index(int wg, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M);
 MK_DEV void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
-  tile_from_index(xcd_remap(bid, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+  tile_from_index(xcd_remap(bid, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn, 8);
 }
-MK_DEV void tile_from_index(int wg, int tiles_m, int tiles_n, int& tm, int& tn) {
-  constexpr int GROUP_M = 8;
+MK_DEV void tile_from_index(int wg, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M = 8) {
   const int per_group = GROUP_M * tiles_n;
   const int group = wg / per_group;
   const int first_m = group * GROUP_M;
@@ -601,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
       zlin = t / per;
       t -= zlin * per;
     }
-    tile_from_index(t, g.tiles_m, g.tiles_n, tm, tn);
+    tile_from_index(t, g.tiles_m, g.tiles_n, tm, tn, (g.ablate >> 8) ? (g.ablate >> 8) : 8);
   }
   const int z = g.lin_batch ? zlin : (int)blockIdx.z, z1 = z / g.nb2, z2 = z - z1 * g.nb2;
   const bf16* A = reinterpret_cast<const bf16*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
@@ -681,10 +680,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
   } while (0)
 #define MK_V2_MFMA4(F)                                                                           \
   do {                                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                               \
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[2], F[0], acc[0][0], 0, 0, 0);         \
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[3], F[0], acc[0][1], 0, 0, 0);         \
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[2], F[1], acc[1][0], 0, 0, 0);         \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[3], F[1], acc[1][1], 0, 0, 0);         \
+    __builtin_amdgcn_s_setprio(0);                                                               \
   } while (0)
 // fragments of k-step ks+1 are requested before the MFMAs of k-step ks (two register sets)
 #define MK_V2_COMPUTE(STAGE)                                                                     \
@@ -844,12 +845,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g) {
   {
     const int bid = blockIdx.x;
     if (bid < g.dp_tiles) {
-      tile_from_index(xcd_remap(bid, g.dp_tiles), g.tiles_m, g.tiles_n, tm, tn);
+      tile_from_index(xcd_remap(bid, g.dp_tiles), g.tiles_m, g.tiles_n, tm, tn, 8);
     } else {
       const int r = bid - g.dp_tiles;
       tail_idx = r / g.split;
       piece = r - tail_idx * g.split;
-      tile_from_index(g.dp_tiles + tail_idx, g.tiles_m, g.tiles_n, tm, tn);
+      tile_from_index(g.dp_tiles + tail_idx, g.tiles_m, g.tiles_n, tm, tn, 8);
       kt_begin = piece * g.kt_per_piece;
       kt_end = min(kt_end, kt_begin + g.kt_per_piece);
     }

@@ -105,13 +105,27 @@ def _c2(x: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
 # LLaMA decoder layer  (modeling.py:234-299)
 # =========================================================================
 class LlamaLayerFn(torch.autograd.Function):
+    """wqkv / wgu (optional, not differentiated) are [3D, D] / [2FF, D] tensors that ALIAS the
+    storage of (wq, wk, wv) / (wg, wu) when LlamaDecoderLayer.fuse_projections() has laid the
+    parameters out contiguously: the three (two) projections then run as ONE GEMM in forward,
+    grad-input and grad-weight (better tile quantisation, 7 fewer launches per layer and pass);
+    the weight gradients are returned as row slices of the fused gradient."""
+
     @staticmethod
-    def forward(ctx, x, kmask, pos, cos, sin, n_heads, eps, wq, wk, wv, wo, wg, wu, wd, ln1, ln2):
+    def forward(ctx, x, kmask, pos, cos, sin, n_heads, eps, wq, wk, wv, wo, wg, wu, wd, ln1, ln2,
+                wqkv=None, wgu=None):
         B, S, D = x.shape
         M, H, hd = B * S, n_heads, D // n_heads
+        FF = wg.shape[0]
         x2 = _c2(x, M, D)
         _, y1, rstd1 = ops.rmsnorm_fwd(x2, ln1, eps)
-        q, k, v = ops.linear_fwd(y1, wq), ops.linear_fwd(y1, wk), ops.linear_fwd(y1, wv)
+        if wqkv is not None:
+            qkv = ops.linear_fwd(y1, wqkv)                    # [M, 3D]
+            q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+            ldq = 3 * D
+        else:
+            q, k, v = ops.linear_fwd(y1, wq), ops.linear_fwd(y1, wk), ops.linear_fwd(y1, wv)
+            qkv, ldq = None, D
         ops.rope_(q, cos, sin, pos, H, hd)
         ops.rope_(k, cos, sin, pos, H, hd)
         att = torch.empty((M, D), dtype=x.dtype, device=x.device)
@@ -121,66 +135,95 @@ class LlamaLayerFn(torch.autograd.Function):
             # fused attention: the S x S scores never reach HBM; training keeps only the
             # per-row log-sum-exp and recomputes P in the fused backward
             lse = torch.empty((B, H, S), dtype=torch.float32, device=x.device) if grad_mode else None
-            ops.flash_attn_fwd(q, k, v, att, B, H, S, S, hd, D, S * D, D, S * D, D, S * D, D, S * D,
-                               1.0 / math.sqrt(hd), kmask=kmask, causal=True, lse=lse)
+            ops.flash_attn_fwd(q, k, v, att, B, H, S, S, hd, ldq, S * ldq, ldq, S * ldq, ldq, S * ldq,
+                               D, S * D, 1.0 / math.sqrt(hd), kmask=kmask, causal=True, lse=lse)
             probs = lse
         else:
-            probs, _ = attention_fwd(TDesc(q, D, S * D), TDesc(k, D, S * D), TDesc(v, D, S * D),
-                                     TDesc(att, D, S * D), B, H, S, S, hd, 1.0 / math.sqrt(hd),
-                                     kmask=kmask, causal=True)
+            probs, _ = attention_fwd(TDesc(q, ldq, S * ldq), TDesc(k, ldq, S * ldq),
+                                     TDesc(v, ldq, S * ldq), TDesc(att, D, S * D), B, H, S, S, hd,
+                                     1.0 / math.sqrt(hd), kmask=kmask, causal=True)
         h1 = ops.linear_fwd(att, wo, residual=x2)
         _, y2, rstd2 = ops.rmsnorm_fwd(h1, ln2, eps)
-        g, u = ops.linear_fwd(y2, wg), ops.linear_fwd(y2, wu)
-        a = ops.swiglu_fwd(g, u)
+        if wgu is not None:
+            gu = ops.linear_fwd(y2, wgu)                      # [M, 2FF] = [gate | up]
+            a = ops.swiglu2d_fwd(gu, FF)
+            g = u = None
+        else:
+            g, u = ops.linear_fwd(y2, wg), ops.linear_fwd(y2, wu)
+            a = ops.swiglu_fwd(g, u)
+            gu = None
         out = ops.linear_fwd(a, wd, residual=h1)
         if grad_mode:
-            ctx.save_for_backward(x2, rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, a, pos,
-                                  cos, sin, wq, wk, wv, wo, wg, wu, wd, ln1, ln2, kmask)
-            ctx.dims = (B, S, D, H, hd, use_flash)
+            ctx.save_for_backward(x2, rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, gu, a, pos,
+                                  cos, sin, wq, wk, wv, wo, wg, wu, wd, ln1, ln2, kmask, wqkv, wgu)
+            ctx.dims = (B, S, D, H, hd, use_flash, FF)
         return out.view(B, S, D)
 
     @staticmethod
     def backward(ctx, dout):
-        (x2, rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, a, pos, cos, sin, wq, wk, wv, wo,
-         wg, wu, wd, ln1, ln2, kmask) = ctx.saved_tensors
-        B, S, D, H, hd, use_flash = ctx.dims
+        (x2, rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, gu, a, pos, cos, sin, wq, wk, wv,
+         wo, wg, wu, wd, ln1, ln2, kmask, wqkv, wgu) = ctx.saved_tensors
+        B, S, D, H, hd, use_flash, FF = ctx.dims
         M = B * S
         need = ctx.needs_input_grad
         dout2 = _c2(dout, M, D)
         # ---- MLP
         da = ops.linear_dx(dout2, wd)
         dwd = ops.linear_dw(dout2, a) if need[13] else None
-        dg, du = ops.swiglu_bwd(g, u, da)
-        del da
-        dy2 = ops.linear_dx(dg, wg)
-        ops.linear_dx(du, wu, out=dy2, accumulate=True)
-        dwg = ops.linear_dw(dg, y2) if need[11] else None
-        dwu = ops.linear_dw(du, y2) if need[12] else None
-        del dg, du
+        dwg = dwu = None
+        if gu is not None:
+            dgu = ops.swiglu2d_bwd(gu, da, FF)
+            del da
+            dy2 = ops.linear_dx(dgu, wgu)
+            if need[11] or need[12]:
+                dwgu = ops.linear_dw(dgu, y2)                  # [2FF, D]
+                dwg, dwu = dwgu[:FF], dwgu[FF:]
+            del dgu
+        else:
+            dg, du = ops.swiglu_bwd(g, u, da)
+            del da
+            dy2 = ops.linear_dx(dg, wg)
+            ops.linear_dx(du, wu, out=dy2, accumulate=True)
+            dwg = ops.linear_dw(dg, y2) if need[11] else None
+            dwu = ops.linear_dw(du, y2) if need[12] else None
+            del dg, du
         dh1, dln2 = ops.rmsnorm_bwd(dy2, h1, ln2, rstd2, dres=dout2)
         # ---- attention
         datt = ops.linear_dx(dh1, wo)
         dwo = ops.linear_dw(dh1, att) if need[10] else None
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        d = lambda t: TDesc(t, D, S * D)  # noqa: E731
-        if use_flash:
-            ops.flash_attn_bwd(q, k, v, att, datt, probs, dq, dk, dv, B, H, S, S, hd, D, S * D, D,
-                               S * D, D, S * D, D, S * D, 1.0 / math.sqrt(hd), kmask=kmask,
-                               causal=True)
+        ldq = q.stride(0)
+        if wqkv is not None:
+            dqkv = torch.empty((M, 3 * D), dtype=q.dtype, device=q.device)
+            dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
         else:
-            attention_bwd(d(datt), d(q), d(k), d(v), probs, None, d(dq), d(dk), d(dv), B, H, S, S,
-                          hd, 1.0 / math.sqrt(hd))
+            dqkv = None
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        if use_flash:
+            ops.flash_attn_bwd(q, k, v, att, datt, probs, dq, dk, dv, B, H, S, S, hd, ldq, S * ldq,
+                               ldq, S * ldq, ldq, S * ldq, D, S * D, 1.0 / math.sqrt(hd),
+                               kmask=kmask, causal=True)
+        else:
+            d = lambda t: TDesc(t, ldq, S * ldq)  # noqa: E731
+            attention_bwd(TDesc(datt, D, S * D), d(q), d(k), d(v), probs, None, d(dq), d(dk), d(dv),
+                          B, H, S, S, hd, 1.0 / math.sqrt(hd))
         ops.rope_(dq, cos, sin, pos, H, hd, inverse=True)
         ops.rope_(dk, cos, sin, pos, H, hd, inverse=True)
-        dy1 = ops.linear_dx(dq, wq)
-        ops.linear_dx(dk, wk, out=dy1, accumulate=True)
-        ops.linear_dx(dv, wv, out=dy1, accumulate=True)
-        dwq = ops.linear_dw(dq, y1) if need[7] else None
-        dwk = ops.linear_dw(dk, y1) if need[8] else None
-        dwv = ops.linear_dw(dv, y1) if need[9] else None
+        dwq = dwk = dwv = None
+        if wqkv is not None:
+            dy1 = ops.linear_dx(dqkv, wqkv)
+            if need[7] or need[8] or need[9]:
+                dwqkv = ops.linear_dw(dqkv, y1)                # [3D, D]
+                dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]
+        else:
+            dy1 = ops.linear_dx(dq, wq)
+            ops.linear_dx(dk, wk, out=dy1, accumulate=True)
+            ops.linear_dx(dv, wv, out=dy1, accumulate=True)
+            dwq = ops.linear_dw(dq, y1) if need[7] else None
+            dwk = ops.linear_dw(dk, y1) if need[8] else None
+            dwv = ops.linear_dw(dv, y1) if need[9] else None
         dx, dln1 = ops.rmsnorm_bwd(dy1, x2, ln1, rstd1, dres=dh1)
         return (dx.view(B, S, D), None, None, None, None, None, None, dwq, dwk, dwv, dwo, dwg, dwu,
-                dwd, dln1 if need[14] else None, dln2 if need[15] else None)
+                dwd, dln1 if need[14] else None, dln2 if need[15] else None, None, None)
 
 
 # =========================================================================

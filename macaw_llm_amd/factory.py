@@ -26,13 +26,17 @@ def make_config(cfg: dict) -> M.MM_LLMs_Config:
                             llm_config=LlamaConfig(**cfg["llama"]), **cfg["mm"])
 
 
-def build_model(cfg: dict, dtype=torch.bfloat16, device="cuda", seed=1234, freeze_encoders=True):
+def build_model(cfg: dict, dtype=torch.bfloat16, device="cuda", seed=1234, freeze_encoders=True,
+                fuse=True):
     """Random-init model of the given architecture, parameters created on `device` in `dtype`.
     freeze_encoders mirrors run_clm_llms.py:390-393 (every '*encoder*' parameter frozen)."""
     torch.manual_seed(seed)
     with _default_dtype(dtype), torch.device(device):
         model = M.MM_LLMs(make_config(cfg))
     model = model.to(device=device, dtype=dtype)
+    if fuse:
+        for layer in model.llm.model.layers:
+            layer.fuse_projections()
     if freeze_encoders:
         for n, p in model.named_parameters():
             p.requires_grad_("encoder" not in n)

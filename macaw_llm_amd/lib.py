@@ -64,6 +64,8 @@ SIGNATURES = {
     "mk_rope": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _i32, _vp],
     "mk_swiglu_fwd": [_vp, _vp, _vp, _i64, _i32, _vp],
     "mk_swiglu_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "mk_swiglu2d_fwd": [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _i32, _vp],
+    "mk_swiglu2d_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i32, _vp],
     "mk_act_fwd": [_vp, _vp, _i64, _i32, _i32, _vp],
     "mk_act_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "mk_add": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],

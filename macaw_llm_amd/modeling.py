@@ -114,18 +114,52 @@ class LlamaDecoderLayer(nn.Module):
         self.input_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
+    # ---- optional fused storage for q|k|v and gate|up ------------------------------------
+    @torch.no_grad()
+    def fuse_projections(self):
+        """Re-home q/k/v (and gate/up) weights in ONE contiguous [3D, D] ([2FF, D]) buffer each;
+        the nn.Linear parameters become row-slice views of it, so state-dict keys, optimizers
+        and gradients are unchanged while the engine runs one GEMM instead of three (two)."""
+        a, m = self.self_attn, self.mlp
+        for mods in ((a.q_proj, a.k_proj, a.v_proj), (m.gate_proj, m.up_proj)):
+            ws = [x.weight for x in mods]
+            fused = torch.cat([w.data for w in ws], dim=0).contiguous()
+            off = 0
+            for w in ws:
+                w.data = fused[off:off + w.shape[0]]
+                off += w.shape[0]
+        return self
+
+    @staticmethod
+    def _fused_view(ws):
+        """[sum rows, D] tensor aliasing the parameters if they are laid out back to back"""
+        w0 = ws[0]
+        ptr, es = w0.data_ptr(), w0.element_size()
+        rows = 0
+        for w in ws:
+            if (not w.is_contiguous() or w.data_ptr() != ptr + rows * w0.shape[1] * es
+                    or w.dtype != w0.dtype or w.shape[1] != w0.shape[1]):
+                return None
+            rows += w.shape[0]
+        try:
+            return w0.data.as_strided((rows, w0.shape[1]), (w0.shape[1], 1))
+        except RuntimeError:   # not inside one storage
+            return None
+
     def forward(self, hidden_states, kmask=None, pos=None, past_key_value=None, use_cache=False):
         """hidden_states [B,S,D]; kmask int32 [B,S] (0 = padding) or None; pos int32 [B*S]."""
         if past_key_value is not None or use_cache:
             raise NotImplementedError("KV-cache decode goes through LlamaForCausalLM.generate")
         a, m = self.self_attn, self.mlp
+        wqkv = self._fused_view((a.q_proj.weight, a.k_proj.weight, a.v_proj.weight))
+        wgu = self._fused_view((m.gate_proj.weight, m.up_proj.weight))
         cos, sin = a.rotary_emb.tables(hidden_states.shape[1], hidden_states.dtype,
                                        hidden_states.device)
         out = eng.LlamaLayerFn.apply(
             hidden_states, kmask, pos, cos, sin, a.num_heads, self.input_layernorm.variance_epsilon,
             a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.o_proj.weight, m.gate_proj.weight,
             m.up_proj.weight, m.down_proj.weight, self.input_layernorm.weight,
-            self.post_attention_layernorm.weight)
+            self.post_attention_layernorm.weight, wqkv, wgu)
         return (out,)
 
 

@@ -247,6 +247,29 @@ def swiglu_bwd(g, u, da):
     return dg, du
 
 
+def swiglu2d_fwd(gu, cols):
+    """gu [rows, 2*cols] = [gate | up]; returns a [rows, cols] = silu(gate) * up"""
+    lib = _L.load()
+    rows = gu.shape[0]
+    a = torch.empty((rows, cols), dtype=gu.dtype, device=gu.device)
+    es = gu.element_size()
+    _L.check(lib.mk_swiglu2d_fwd(_p(gu), _p(gu) + cols * es, _p(a), rows, cols, gu.stride(0), cols,
+                                 dt(gu), _st()), "mk_swiglu2d_fwd")
+    return a
+
+
+def swiglu2d_bwd(gu, da, cols):
+    """returns dgu [rows, 2*cols] = [dgate | dup]"""
+    lib = _L.load()
+    rows = gu.shape[0]
+    dgu = torch.empty_like(gu)
+    es = gu.element_size()
+    _L.check(lib.mk_swiglu2d_bwd(_p(gu), _p(gu) + cols * es, _p(da), _p(dgu), _p(dgu) + cols * es,
+                                 rows, cols, gu.stride(0), da.stride(0), dt(gu), _st()),
+             "mk_swiglu2d_bwd")
+    return dgu
+
+
 def act_fwd(x, act):
     lib = _L.load()
     y = torch.empty_like(x)

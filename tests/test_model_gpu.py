@@ -15,7 +15,7 @@ from golden_util import load_case  # noqa: E402
 from oracle import configs  # noqa: E402
 
 
-def build_model(cfg, state, dtype, dev, freeze_encoders=True):
+def build_model(cfg, state, dtype, dev, freeze_encoders=True, fuse=False):
     from transformers import CLIPConfig, LlamaConfig, WhisperConfig
     from macaw_llm_amd import modeling as M
     mm = M.MM_LLMs_Config(clip_config=CLIPConfig(**cfg["clip"]), whisper_config=WhisperConfig(**cfg["whisper"]),
@@ -24,6 +24,9 @@ def build_model(cfg, state, dtype, dev, freeze_encoders=True):
     missing, unexpected = model.load_state_dict(state, strict=False)
     assert not unexpected, unexpected
     model = model.to(dev).to(dtype)
+    if fuse:  # q|k|v and gate|up weights re-homed in contiguous storage -> single GEMMs
+        for layer in model.llm.model.layers:
+            layer.fuse_projections()
     if freeze_encoders:  # run_clm_llms.py:390-393
         for n, p in model.named_parameters():
             p.requires_grad_("encoder" not in n)
@@ -34,11 +37,15 @@ def to_dev(inputs, dev):
     return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inputs.items()}
 
 
+@pytest.mark.parametrize("fuse", [False, True])
 @pytest.mark.parametrize("case", ["micro_all", "micro_image"])
-def test_forward_backward_fp32_matches_reference(dev, case):
+def test_forward_backward_fp32_matches_reference(dev, case, fuse):
     fx = load_case(case)
     cfg = configs.get(fx["config_name"])
-    model = build_model(cfg, fx["state"], torch.float32, dev).eval()
+    model = build_model(cfg, fx["state"], torch.float32, dev, fuse=fuse).eval()
+    if fuse:
+        l0 = model.llm.model.layers[0]
+        assert l0._fused_view((l0.mlp.gate_proj.weight, l0.mlp.up_proj.weight)) is not None
     inp = to_dev(fx["inputs"], dev)
     emb, am, lab = model.prepare_inputs_for_generation(inp)
     assert torch.equal(am.cpu(), fx["attention_mask"])          # INT: bit exact
@@ -64,11 +71,12 @@ def test_forward_backward_fp32_matches_reference(dev, case):
         assert named[name].grad is None, name
 
 
+@pytest.mark.parametrize("fuse", [False, True])
 @pytest.mark.parametrize("case", ["micro_all", "micro_image"])
-def test_forward_backward_bf16(dev, case):
+def test_forward_backward_bf16(dev, case, fuse):
     fx = load_case(case)
     cfg = configs.get(fx["config_name"])
-    model = build_model(cfg, fx["state"], torch.bfloat16, dev).eval()
+    model = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=fuse).eval()
     inp = to_dev(fx["inputs"], dev)
     inp = {k: (v.half() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}  # llm_trainer.py:366-368
     out = model(inputs=inp)
