@@ -71,3 +71,49 @@ def test_shard_batch():
     assert [shard_batch(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]
     with pytest.raises(ValueError):
         shard_batch(10, 0, 4)
+
+
+def _worker_overlapped(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from macaw_llm_amd.train import OverlappedStep
+
+        class SGD:  # stands in for FusedAdamW (whose kernel needs the GPU)
+            step_count = 0
+
+            def step_param(self, p):
+                p.data -= 0.5 * p.grad
+
+        torch.manual_seed(0)
+        big = torch.nn.Parameter(torch.randn(40, 30))
+        small = torch.nn.Parameter(torch.randn(5))
+        w0, s0 = big.detach().clone(), small.detach().clone()
+        rt = OverlappedStep([big, small], SGD(), small_threshold=100)
+        ok = True
+        for it in range(2):
+            rt.begin()
+            ((big * (rank + 1)).sum() + (small * (2 * rank + 1)).sum()).backward()
+            rt.finish()
+            w0 = w0 - 0.5 * 1.5          # mean over ranks of (rank + 1)
+            s0 = s0 - 0.5 * 2.0          # mean over ranks of (2 rank + 1)
+            ok = ok and torch.allclose(big.data, w0) and torch.allclose(small.data, s0)
+        ok = ok and rt.opt.step_count == 2
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_step_gloo_world2():
+    """train.OverlappedStep: replicas stay identical and equal to SGD on the rank-mean gradient"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlapped, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
