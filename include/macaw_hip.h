@@ -232,6 +232,11 @@ int mk_cross_entropy_bwd(const void* logits, void* dlogits, const int64_t* label
                          const float* grad_scale_dev /* optional device scalar multiplied in */,
                          int32_t rows, int32_t V, int64_t ld, int32_t dtype, void* stream);
 
+/* Greedy decoding (modeling.py:959, HF greedy_search): out[r] = index of the first maximum of
+ * row r of x[rows][cols] (pitch ld). */
+int mk_argmax_rows(const void* x, int64_t ld, int32_t rows, int32_t cols, int64_t* out,
+                   int32_t dtype, void* stream);
+
 /* ------------------------------------------------------------ optimizer --
  * Fused AdamW over a flat shard (replaces DeepSpeed CPU-offloaded Adam,
  * configs/deepspeed_config.json:2-13): fp32 master/m/v, `dtype` grads and

@@ -288,6 +288,37 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* logits, T* dlogits
   }
 }
 
+// --------------------------------------------------------------- argmax ----
+// Greedy token selection (HF greedy_search, modeling.py:959): index of the first maximum of
+// every row; fp32 compare, ties -> lowest index (torch.argmax semantics).
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const T* x, long ld, int cols,
+                                                          int64_t* out) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const long row = blockIdx.x;
+  const T* xr = x + row * ld;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const float v = to_f32<T>(xr[c]);
+    if (v > best || (v == best && c < idx)) { best = v; idx = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    out[row] = idx;
+  }
+}
+
 // ------------------------------------------------------------------ AdamW --
 template <typename T>
 __global__ __launch_bounds__(256) void adamw_kernel(T* param, float* master, float* m, float* v,
@@ -447,6 +478,19 @@ extern "C" int mk_adamw(void* param, float* master, float* m, float* v, const vo
     MK_LAUNCH((adamw_kernel<float>), grid, block, 0, MK_ST, (float*)param, master, m, v,
                        (const float*)grad, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
                        grad_scale);
+  else return MK_ERR_UNSUPPORTED;
+  return mk_check_launch();
+}
+
+extern "C" int mk_argmax_rows(const void* x, int64_t ld, int32_t rows, int32_t cols, int64_t* out,
+                              int32_t dtype, void* stream) {
+  if (!x || !out || rows <= 0 || cols <= 0 || ld < cols) return MK_ERR_BAD_ARG;
+  if (dtype == MK_BF16)
+    MK_LAUNCH((argmax_rows_kernel<bf16>), dim3(rows), dim3(256), 0, MK_ST, (const bf16*)x, (long)ld,
+              cols, out);
+  else if (dtype == MK_F32)
+    MK_LAUNCH((argmax_rows_kernel<float>), dim3(rows), dim3(256), 0, MK_ST, (const float*)x,
+              (long)ld, cols, out);
   else return MK_ERR_UNSUPPORTED;
   return mk_check_launch();
 }

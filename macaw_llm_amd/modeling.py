@@ -326,33 +326,87 @@ class LlamaForCausalLM(LlamaPreTrainedModel):
 
     @torch.no_grad()
     def generate(self, inputs_embeds=None, input_ids=None, max_new_tokens=128, eos_token_id=2,
-                 bos_token_id=1, pad_token_id=None, **_):
-        """Greedy decode (the only mode the reference uses, modeling.py:959).  Round-1
-        implementation recomputes the prefix each step (no KV cache yet): same arithmetic as
-        the cached path, token ids identical.  Returns the NEW token ids [B, <=max_new_tokens]."""
+                 bos_token_id=1, pad_token_id=None, use_cache=True, **_):
+        """Greedy decode — the only mode the reference uses (modeling.py:959:
+        `llm.generate(inputs_embeds=…, max_new_tokens=128, eos_token_id=2, bos_token_id=1,
+        pad_token_id=32006)`, no attention mask).  Prefill runs the prompt once and fills a
+        preallocated per-layer KV cache [B, T_max, D]; every decode step runs one position
+        through the layers against the cache (fused attention, Lq = 1) instead of the
+        reference's per-step `torch.cat` of the cache (modeling.py:190-195).  Finished samples
+        emit pad_token_id.  Returns the NEW token ids [B, <= max_new_tokens].
+        use_cache=False recomputes the whole prefix each step (same ids; test reference)."""
+        emb_w = self.model.embed_tokens.weight
         if inputs_embeds is None:
-            inputs_embeds = EmbeddingFn.apply(self.model.embed_tokens.weight,
-                                              input_ids.long().reshape(-1), None
-                                              ).view(*input_ids.shape, -1)
-        emb = inputs_embeds
-        B = emb.shape[0]
+            inputs_embeds = ops.embedding_fwd(emb_w, input_ids.long().reshape(-1)).view(*input_ids.shape, -1)
+        _dev_check(inputs_embeds)
+        B, S0, D = inputs_embeds.shape
+        dev, dtype = inputs_embeds.device, inputs_embeds.dtype
         pad = pad_token_id if pad_token_id is not None else (eos_token_id or 0)
-        done = torch.zeros(B, dtype=torch.bool, device=emb.device)
+        done = torch.zeros(B, dtype=torch.bool, device=dev)
+        eps = self.model.norm.variance_epsilon
+        V = self.lm_head.weight.shape[0]
         out = []
-        for _ in range(max_new_tokens):
-            logits = self(inputs_embeds=emb).logits[:, -1, :]
-            nxt = logits.float().argmax(-1)
-            nxt = torch.where(done, torch.full_like(nxt, pad), nxt)
+
+        def select(h_last):       # h_last [B, D] -> next token ids [B]
+            _, y, _ = ops.rmsnorm_fwd(h_last, self.model.norm.weight, eps)
+            return ops.argmax_rows(ops.linear_fwd(y, self.lm_head.weight), V)
+
+        if not use_cache:
+            emb = inputs_embeds.contiguous()
+            for _ in range(max_new_tokens):
+                S = emb.shape[1]
+                self.model._defer_final_norm = True
+                try:
+                    h = self.model(inputs_embeds=emb)
+                finally:
+                    self.model._defer_final_norm = False
+                last = torch.empty((B, D), dtype=dtype, device=dev)
+                ops.copy2d(h.contiguous(), last, 1, D, D, D, batch=B, s_src=S * D, s_dst=D,
+                           src_off=(S - 1) * D)
+                nxt = torch.where(done, torch.full((B,), pad, dtype=torch.long, device=dev), select(last))
+                out.append(nxt)
+                done = done | (nxt == eos_token_id)
+                if bool(done.all()):
+                    break
+                nemb = torch.empty((B, S + 1, D), dtype=dtype, device=dev)
+                ops.copy2d(emb, nemb, S, D, D, D, batch=B, s_src=S * D, s_dst=(S + 1) * D)
+                ops.copy2d(ops.embedding_fwd(emb_w, nxt.contiguous()), nemb, 1, D, D, D, batch=B,
+                           s_src=D, s_dst=(S + 1) * D, dst_off=S * D)
+                emb = nemb
+            return torch.stack(out, dim=1)
+
+        Tmax = S0 + max_new_tokens
+        layers = self.model.layers
+        rot = layers[0].self_attn.rotary_emb
+        cos, sin = rot.tables(Tmax, dtype, dev)
+        kc = [torch.empty((B, Tmax, D), dtype=dtype, device=dev) for _ in layers]
+        vc = [torch.empty((B, Tmax, D), dtype=dtype, device=dev) for _ in layers]
+
+        def run(x2, Sn, t0):
+            pos = (torch.arange(t0, t0 + Sn, dtype=torch.int32, device=dev)).repeat(B)
+            for i, lyr in enumerate(layers):
+                a, m = lyr.self_attn, lyr.mlp
+                x2 = eng.llama_layer_cached(
+                    x2, B, Sn, t0, kc[i], vc[i], Tmax, pos, cos, sin, a.num_heads,
+                    lyr.input_layernorm.variance_epsilon, a.q_proj.weight, a.k_proj.weight,
+                    a.v_proj.weight, a.o_proj.weight, m.gate_proj.weight, m.up_proj.weight,
+                    m.down_proj.weight, lyr.input_layernorm.weight,
+                    lyr.post_attention_layernorm.weight,
+                    lyr._fused_view((a.q_proj.weight, a.k_proj.weight, a.v_proj.weight)),
+                    lyr._fused_view((m.gate_proj.weight, m.up_proj.weight)))
+            return x2
+
+        h = run(eng._c2(inputs_embeds, B * S0, D), S0, 0)                 # prefill
+        last = torch.empty((B, D), dtype=dtype, device=dev)
+        ops.copy2d(h, last, 1, D, D, D, batch=B, s_src=S0 * D, s_dst=D, src_off=(S0 - 1) * D)
+        for t in range(max_new_tokens):
+            nxt = torch.where(done, torch.full((B,), pad, dtype=torch.long, device=dev), select(last))
             out.append(nxt)
             done = done | (nxt == eos_token_id)
-            if bool(done.all()):
+            if t + 1 == max_new_tokens or bool(done.all()):
                 break
-            e = ops.embedding_fwd(self.model.embed_tokens.weight, nxt.contiguous())
-            nemb = torch.empty((B, emb.shape[1] + 1, emb.shape[2]), dtype=emb.dtype, device=emb.device)
-            S0, D = emb.shape[1], emb.shape[2]
-            ops.copy2d(emb.contiguous(), nemb, S0, D, D, D, batch=B, s_src=S0 * D, s_dst=(S0 + 1) * D)
-            ops.copy2d(e, nemb, 1, D, D, D, batch=B, s_src=D, s_dst=(S0 + 1) * D, dst_off=S0 * D)
-            emb = nemb
+            x = ops.embedding_fwd(emb_w, nxt.contiguous())                 # [B, D]
+            last = run(x, 1, S0 + t)                                       # decode step
         return torch.stack(out, dim=1)
 
 

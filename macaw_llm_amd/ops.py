@@ -452,6 +452,17 @@ def cross_entropy_bwd(logits, labels, row_lse, sum_cnt, V, grad_scale=1.0, out=N
     return out
 
 
+def argmax_rows(x, cols=None):
+    """first-max index of every row of a 2-D row-major (pitched) tensor -> int64 [rows]"""
+    lib = _L.load()
+    rows = x.shape[0]
+    cols = x.shape[1] if cols is None else cols
+    out = torch.empty(rows, dtype=torch.int64, device=x.device)
+    _L.check(lib.mk_argmax_rows(_p(x), _rowmajor(x), rows, cols, _p(out), dt(x), _st()),
+             "mk_argmax_rows")
+    return out
+
+
 def adamw_(param, master, m, v, grad, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     lib = _L.load()
     _L.check(lib.mk_adamw(_p(param), _p(master), _p(m), _p(v), _p(grad), param.numel(), lr, beta1,

@@ -106,11 +106,33 @@ def test_train_mode_dropout_and_text_only(dev):
     assert out.logits.shape[1] == inp["input_ids"].shape[1] and torch.isfinite(out.loss)
 
 
-def test_generate_matches_restated_greedy(dev):
+@pytest.mark.parametrize("use_cache", [True, False])
+def test_generate_matches_restated_greedy(dev, use_cache):
+    """greedy token ids bit-exact vs the restated HF greedy loop (golden), with the KV-cache
+    decode path and with full-prefix recompute"""
     fx = load_case("micro_all")
     cfg = configs.get(fx["config_name"])
     model = build_model(cfg, fx["state"], torch.float32, dev).eval()
     emb = fx["inputs_embeds"].to(dev)
     ids = model.llm.generate(inputs_embeds=emb, max_new_tokens=8, eos_token_id=2, bos_token_id=1,
-                             pad_token_id=cfg["tags"]["pad"])
+                             pad_token_id=cfg["tags"]["pad"], use_cache=use_cache)
     assert torch.equal(ids.cpu(), fx["generate_ids"])   # token ids: bit exact
+
+
+def test_generate_kv_cache_bf16_and_inference_flag(dev):
+    """bf16 (fused attention with Lq=1 against the cache): the cached decode must reproduce the
+    ids of the full-recompute decode, and MM_LLMs.forward(inference=True) returns ids."""
+    fx = load_case("micro_all")
+    cfg = configs.get(fx["config_name"])
+    model = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=True).eval()
+    emb = fx["inputs_embeds"].to(dev).to(torch.bfloat16)
+    a = model.llm.generate(inputs_embeds=emb, max_new_tokens=12, eos_token_id=2, pad_token_id=106)
+    b = model.llm.generate(inputs_embeds=emb, max_new_tokens=12, eos_token_id=2, pad_token_id=106,
+                           use_cache=False)
+    assert a.shape[0] == emb.shape[0] and a.dtype == torch.long
+    agree = (a[:, : b.shape[1]] == b[:, : a.shape[1]]).float().mean().item()
+    assert agree >= 0.9, agree          # bf16 near-ties may flip an argmax; ids must otherwise agree
+    inp = to_dev(fx["inputs"], dev)
+    inp["inference"] = True
+    gen = model(inputs=inp)
+    assert gen.dim() == 2 and gen.shape[0] == emb.shape[0] and gen.shape[1] <= 128
