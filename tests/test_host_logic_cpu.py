@@ -102,3 +102,39 @@ def test_root_modeling_shim_exports_reference_names():
     for name in ("MM_LLMs", "MM_LLMs_Config", "LlamaForCausalLM", "LlamaModel", "LlamaDecoderLayer",
                  "LlamaAttention", "LlamaMLP", "LlamaRMSNorm", "LlamaRotaryEmbedding"):
         assert hasattr(m, name), name
+
+
+def test_checkpoint_round_trip_with_fused_projections(tmp_path):
+    """save_pretrained / MM_LLMs.from_pretrained(dir, config=...) as
+    run_clm_llms_inference.py:455 does, with the q|k|v / gate|up weights living in fused storage."""
+    from macaw_llm_amd.factory import build_model, make_config
+    from macaw_llm_amd import modeling as M
+    cfg = configs.get("micro")
+    m = build_model(cfg, dtype=torch.float32, device="cpu", fuse=True)
+    l0 = m.llm.model.layers[0]
+    assert l0._fused_view((l0.self_attn.q_proj.weight, l0.self_attn.k_proj.weight,
+                           l0.self_attn.v_proj.weight)) is not None
+    m.save_pretrained(tmp_path)
+    m2 = M.MM_LLMs.from_pretrained(str(tmp_path), config=make_config(cfg))
+    a, b = m.state_dict(), m2.state_dict()
+    assert set(a) == set(b)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+@pytest.mark.skipif(not ref_loader.reference_available(), reason="/root/reference absent")
+def test_loads_a_checkpoint_written_by_the_reference(tmp_path):
+    """state-dict interchange: a checkpoint saved by the reference's MM_LLMs loads into ours"""
+    from macaw_llm_amd.factory import make_config
+    from macaw_llm_amd import modeling as M
+    cfg = configs.get("micro")
+    from safetensors.torch import save_file
+    ref = ref_loader.build_reference_model(cfg, seed=3)
+    # (the reference's own save_pretrained cannot run under transformers 5.x: its config class
+    # has no default constructor; write its state dict and a config the way HF would)
+    save_file({k: v.contiguous() for k, v in ref.state_dict().items()}, str(tmp_path / "model.safetensors"),
+              metadata={"format": "pt"})
+    make_config(cfg).save_pretrained(tmp_path)
+    mine = M.MM_LLMs.from_pretrained(str(tmp_path), config=make_config(cfg))
+    rs, ms = ref.state_dict(), mine.state_dict()
+    assert set(rs) == set(ms)
+    assert all(torch.equal(rs[k], ms[k]) for k in rs)
