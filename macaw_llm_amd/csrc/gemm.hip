@@ -539,14 +539,21 @@ __global__ __launch_bounds__(BMv * 2) void gemm_bf16_pipe_kernel(GemmArgs g) {
 //     (garbage only reaches discarded outputs), reduction-major over-reads stay inside the
 //     buffer or hit the SRD bound (returns 0).
 // Requires 16-byte aligned operands and K % 64 == 0; anything else runs the generic kernel.
-template <bool RED_MAJOR>
+// K-major LDS image of a [128][BKv] tile: 16-B chunk swizzle (conflict-free ds_read_b128)
+template <int BKv>
+MK_DEV int kswz(int row, int kc) {
+  if constexpr (BKv == 64) return kc ^ ((row >> 1) & 7);
+  else return kc ^ ((row >> 2) & 3);
+}
+template <bool RED_MAJOR, int BKv>
 MK_DEV void v2_voffsets(int row0, int R, long ld, int w, int l, int (&voff)[4]) {
+  constexpr int CR = BKv / 8;          // 16-B chunks per K-major row
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < BKv / 16; ++i) {
     const int p = w + 4 * i;
     if constexpr (!RED_MAJOR) {
-      const int row = p * 8 + (l >> 3);
-      const int kc = (l & 7) ^ ((row >> 1) & 7);
+      const int row = p * (64 / CR) + l / CR;
+      const int kc = kswz<BKv>(row, l % CR);
       const int gr = min(row0 + row, R - 1) - row0;  // may be negative only if row0 >= R (never)
       voff[i] = (int)((long)gr * ld * 2 + kc * 16);
     } else {
@@ -556,7 +563,7 @@ MK_DEV void v2_voffsets(int row0, int R, long ld, int w, int l, int (&voff)[4]) 
     }
   }
 }
-template <bool RED_MAJOR>
+template <bool RED_MAJOR, int BKv>
 MK_DEV void v2_frag_offsets(int wrow0, int l, int (&off)[2][4]) {
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
@@ -564,8 +571,8 @@ MK_DEV void v2_frag_offsets(int wrow0, int l, int (&off)[2][4]) {
       const int row = wrow0 + f * 32 + (l & 31);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const int kc = ks * 2 + (l >> 5);
-        off[f][ks] = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+        const int kc = (ks * 2 + (l >> 5)) % (BKv / 8);
+        off[f][ks] = row * (BKv * 2) + (kswz<BKv>(row, kc) << 4);
       }
     } else {
       const int li = l & 15;
@@ -576,12 +583,15 @@ MK_DEV void v2_frag_offsets(int wrow0, int l, int (&off)[2][4]) {
     }
   }
 }
-template <bool A_RED, bool B_RED>
+template <bool A_RED, bool B_RED, int BKv>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
+  constexpr int TILE_B = 128 * BKv * 2;   // bytes per operand tile
+  constexpr int NP = BKv / 16;            // LDS-DMA pieces per wave per operand tile
+  constexpr int NKS = BKv / 16;           // MFMA k-steps per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
   int piece = -1, tail_idx = 0, zlin = 0;
-  int kt_begin = 0, kt_end = g.K / BK;
+  int kt_begin = 0, kt_end = g.K / BKv;
   {
     const int bid = blockIdx.x;
     int t;
@@ -625,13 +635,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
       (void*)bbase, 0, (int)min(b_bytes, 0x7fffffffL), 0x00020000);
   int voffA[4], voffB[4];
-  v2_voffsets<A_RED>(m0, g.M, g.lda, w, l, voffA);
-  v2_voffsets<B_RED>(n0, g.N, g.ldb, w, l, voffB);
-  const int stepA = A_RED ? (int)(BK * g.lda * 2) : BK * 2;  // bytes per K-tile
-  const int stepB = B_RED ? (int)(BK * g.ldb * 2) : BK * 2;
+  v2_voffsets<A_RED, BKv>(m0, g.M, g.lda, w, l, voffA);
+  v2_voffsets<B_RED, BKv>(n0, g.N, g.ldb, w, l, voffB);
+  const int stepA = A_RED ? (int)(BKv * g.lda * 2) : BKv * 2;  // bytes per K-tile
+  const int stepB = B_RED ? (int)(BKv * g.ldb * 2) : BKv * 2;
   int offA[2][4], offB[2][4];
-  v2_frag_offsets<A_RED>(wm0, l, offA);
-  v2_frag_offsets<B_RED>(wn0, l, offB);
+  v2_frag_offsets<A_RED, BKv>(wm0, l, offA);
+  v2_frag_offsets<B_RED, BKv>(wn0, l, offB);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -643,15 +653,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
 
   int sA = kt_begin * stepA, sB = kt_begin * stepB;  // scalar byte offsets of the next K-tile
   auto issue = [&](int stage) {
-    char* la = smem + stage * (2 * TILE_BYTES) + w * 1024;
+    char* la = smem + stage * (2 * TILE_B) + w * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NP; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rsA, (__attribute__((address_space(3))) void*)(la + i * 4096), 16, voffA[i], sA, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NP; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsB, (__attribute__((address_space(3))) void*)(la + TILE_BYTES + i * 4096), 16, voffB[i],
+          rsB, (__attribute__((address_space(3))) void*)(la + TILE_B + i * 4096), 16, voffB[i],
           sB, 0, 0);
     sA += stepA;
     sB += stepB;
@@ -673,10 +683,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
   }()
 #define MK_V2_LOAD4(DST, KS, STAGE)                                                              \
   do {                                                                                           \
-    DST[0] = MK_V2_FRAG(A_RED, offA, 0, KS, (STAGE) * 2 * TILE_BYTES);                           \
-    DST[1] = MK_V2_FRAG(A_RED, offA, 1, KS, (STAGE) * 2 * TILE_BYTES);                           \
-    DST[2] = MK_V2_FRAG(B_RED, offB, 0, KS, (STAGE) * 2 * TILE_BYTES + TILE_BYTES);              \
-    DST[3] = MK_V2_FRAG(B_RED, offB, 1, KS, (STAGE) * 2 * TILE_BYTES + TILE_BYTES);              \
+    DST[0] = MK_V2_FRAG(A_RED, offA, 0, KS, (STAGE) * 2 * TILE_B);                           \
+    DST[1] = MK_V2_FRAG(A_RED, offA, 1, KS, (STAGE) * 2 * TILE_B);                           \
+    DST[2] = MK_V2_FRAG(B_RED, offB, 0, KS, (STAGE) * 2 * TILE_B + TILE_B);              \
+    DST[3] = MK_V2_FRAG(B_RED, offB, 1, KS, (STAGE) * 2 * TILE_B + TILE_B);              \
   } while (0)
 #define MK_V2_MFMA4(F)                                                                           \
   do {                                                                                           \
@@ -694,10 +704,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
     MK_V2_LOAD4(fa_, 0, STAGE);                                                                  \
     MK_V2_LOAD4(fb_, 1, STAGE);                                                                  \
     MK_V2_MFMA4(fa_);                                                                            \
-    MK_V2_LOAD4(fa_, 2, STAGE);                                                                  \
-    MK_V2_MFMA4(fb_);                                                                            \
-    MK_V2_LOAD4(fb_, 3, STAGE);                                                                  \
-    MK_V2_MFMA4(fa_);                                                                            \
+    if (NKS == 4) {                                                                              \
+      MK_V2_LOAD4(fa_, 2, STAGE);                                                                \
+      MK_V2_MFMA4(fb_);                                                                          \
+      MK_V2_LOAD4(fb_, 3, STAGE);                                                                \
+      MK_V2_MFMA4(fa_);                                                                          \
+    }                                                                                            \
     MK_V2_MFMA4(fb_);                                                                            \
   } while (0)
 #define MK_V2_SYNC()                                          \
@@ -1262,7 +1274,12 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
                        fits(d->a_red_major, d->lda, 256) && fits(d->b_red_major, d->ldb, 256);
       if (!big) cfg = 5;
     }
-    if ((cfg == 5 || cfg == 6) && !v2_ok) cfg = 0;
+    if ((cfg == 5 || cfg == 6 || cfg == 7) && !v2_ok) cfg = 0;
+    // Measured (profiles/): with BOTH operands reduction-major (dW = dy^T x) the global rows are
+    // whole 256-B lines whatever BK is, and BK = 32 (32 KiB LDS -> 4 workgroups per CU) is 17 %
+    // faster (1090-1140 vs 930-980 TFLOP/s); K-major operands would degrade to 64-B segments.
+    if (cfg == 5 && d->a_red_major && d->b_red_major && !getenv("MK_GEMM_NO_BK32")) cfg = 7;
+    const int bkv = cfg == 7 ? 32 : BK;
     rec.cfg = cfg;
     if (cfg >= 3 && cfg != 5 && (d->M <= 128 || (long)mk_cdiv(d->M, 256) * mk_cdiv(d->N, BN) * nbatch < 256)) cfg -= 2;
     const int bm = (cfg == 3 || cfg == 4 || cfg == 6) ? 256 : 128;
@@ -1276,6 +1293,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
               (d->sC1 % 4 == 0) && (d->sC2 % 4 == 0) &&
               (!d->R || (((reinterpret_cast<uintptr_t>(d->R) & 7) == 0) && (d->ldr % 4 == 0) &&
                          (d->sR1 % 4 == 0) && (d->sR2 % 4 == 0)));
+    static const int lds_pad = [] { const char* e = getenv("MK_GEMM_LDS_PAD"); return e ? atoi(e) : 0; }();
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch);
     g.dp_tiles = g.tiles_m * g.tiles_n;
     g.lin_batch = 0;
@@ -1285,14 +1303,14 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
     g.counters = nullptr;
     static const int ablate = [] { const char* e = getenv("MK_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     g.ablate = ablate;
-    if ((cfg == 5 || (cfg == 6 && nbatch == 1)) && d->ws && !getenv("MK_GEMM_NO_STREAMK")) {
+    if ((cfg == 5 || cfg == 7 || (cfg == 6 && nbatch == 1)) && d->ws && !getenv("MK_GEMM_NO_STREAMK")) {
       static const int slots = [] {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return cus;
-      }() * (cfg == 6 ? 1 : 2);  // resident workgroups per CU: two 64-KiB v2 or one 128-KiB v3
-      const int T = g.tiles_m * g.tiles_n * nbatch, nkt = d->K / BK;
+      }() * (cfg == 6 ? 1 : (cfg == 7 ? 4 : 2));  // resident workgroups per CU
+      const int T = g.tiles_m * g.tiles_n * nbatch, nkt = d->K / bkv;
       const int R = T % slots;
       int sp = R > 0 ? slots / R : 1;
       if (sp > nkt / 2) sp = nkt / 2;  // at least two K-tiles per piece
@@ -1339,12 +1357,14 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
   do {                                                                                        \
     static bool attr_done = false;                                                            \
     if (!attr_done) {                                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v2_kernel<AR, BR>),  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v2_kernel<AR, BR, 64>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + lds_pad); \
       attr_done = true;                                                                       \
     }                                                                                         \
-    MK_LAUNCH((gemm_bf16_v2_kernel<AR, BR>), grid, dim3(256), 4 * TILE_BYTES, st, g);         \
+    MK_LAUNCH((gemm_bf16_v2_kernel<AR, BR, 64>), grid, dim3(256), 4 * TILE_BYTES + lds_pad, st, g); \
   } while (0)
+#define MK_V2S(AR, BR)                                                                        \
+  MK_LAUNCH((gemm_bf16_v2_kernel<AR, BR, 32>), grid, dim3(256), 2 * TILE_BYTES, st, g)
 #define MK_V3(AR, BR)                                                                         \
   do {                                                                                        \
     static bool attr_done = false;                                                            \
@@ -1357,7 +1377,8 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
   } while (0)
 #define MK_LAYOUT(AR, BR)                                    \
   do {                                                       \
-    if (cfg == 6) MK_V3(AR, BR);                             \
+    if (cfg == 7) MK_V2S(AR, BR);                            \
+    else if (cfg == 6) MK_V3(AR, BR);                        \
     else if (cfg == 5) MK_V2(AR, BR);                        \
     else if (cfg == 0) MK_REG(AR, BR);                       \
     else if (cfg == 1) MK_PIPE(AR, BR, 128, 2);              \
@@ -1371,6 +1392,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
     else MK_LAYOUT(true, true);
 #undef MK_LAYOUT
 #undef MK_V2
+#undef MK_V2S
 #undef MK_V3
 #undef MK_REG
 #undef MK_PIPE
