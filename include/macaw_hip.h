@@ -245,6 +245,36 @@ int mk_adamw(void* param, float* master, float* m, float* v, const void* grad, i
              float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
              float grad_scale, int32_t dtype, void* stream);
 
+/* ------------------------------------------------------ host-input pipeline --
+ * The per-step CPU work of llm_trainer.py:306-381 (get_self_inputs) moved to the GPU.
+ *
+ * mk_image_transform = CLIP `_transform(n_px)` (llm_trainer.py:150-157): torchvision
+ * Resize(n_px, BICUBIC) on a PIL image -> CenterCrop(n_px) -> ToTensor -> Normalize, for a batch
+ * of RGB uint8 HWC images of different sizes packed back to back in `src`.  Bit-exact with
+ * Pillow 12.2 ImagingResample (libImaging/Resample.c): the host computes Pillow's 22-bit
+ * fixed-point bicubic coefficients (macaw_llm_amd/preprocess.py) for the cropped window only.
+ *   descs  : n_images x 12 int64 {src_off, H, W, tmp_off, row0, nrows, hk_off, hb_off, hks,
+ *            vk_off, vb_off, vks}  (offsets into src/tmp in bytes, into coef in int32 elements)
+ *   coef   : int32 coefficient rows [out_px][ks] and bounds [out_px][2] = {first tap, n taps}
+ *   lut    : float[3][256] = ((v / 255) - mean[c]) / std[c] as the reference evaluates it
+ *   tmp    : scratch for the horizontally resampled rows (sum of nrows * out_px * 3 bytes)
+ *   out    : [n_images][3][out_px][out_px] in `dtype` (MK_F32 / MK_BF16 / MK_F16) */
+int mk_image_transform(const uint8_t* src, uint8_t* tmp, const int64_t* descs, const int32_t* coef,
+                       const float* lut, void* out, int32_t n_images, int32_t out_px,
+                       int64_t max_tmp_rows, int32_t dtype, void* stream);
+
+/* mk_log_mel = whisper.log_mel_spectrogram (llm_trainer.py:343, openai-whisper audio.py):
+ * torch.stft(audio, 400, 160, hann, center/reflect) -> |.|^2 without the last frame ->
+ * mel_filters[n_mels][201] @ . -> log10(clamp 1e-10) -> max(., per-clip max - 8) -> (. + 4) / 4.
+ * audio [n_clips][ld] f32 with n_samples (multiple of 160) valid samples per clip;
+ * window f32[400]; twiddle f64[400][2] = (cos, sin)(2 pi j / 400); mel_lo/mel_hi = first / one
+ * past last non-zero bin of each filter; ws_logspec f32[n_clips * n_mels * n_samples/160],
+ * ws_max int32[n_clips]; out [n_clips][n_mels][n_samples/160] in `dtype`. */
+int mk_log_mel(const float* audio, int64_t ld, int32_t n_clips, int32_t n_samples,
+               const float* window, const double* twiddle, const float* mel_filters,
+               const int32_t* mel_lo, const int32_t* mel_hi, int32_t n_mels, float* ws_logspec,
+               int32_t* ws_max, void* out, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

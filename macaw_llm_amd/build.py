@@ -19,7 +19,8 @@ CSRC = PKG / "csrc"
 OBJ = PKG / "csrc" / "_obj"
 LIB = PKG / "libmacaw_hip.so"
 ARCH = "gfx950"
-SOURCES = ["gemm.hip", "norm.hip", "elementwise.hip", "softmax.hip", "attention.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "elementwise.hip", "softmax.hip", "attention.hip",
+           "preprocess.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
          "-Wno-unused-result"]
 

@@ -437,6 +437,10 @@ extern "C" int mk_add(const void* a, const void* b, void* y, int64_t n, int64_t 
 }
 extern "C" int mk_fill(void* p, float v, int64_t n, int32_t dtype, void* stream) {
   if (!p || n <= 0) return MK_ERR_BAD_ARG;
+  if (dtype == MK_F16) {   // fp16 only carries the reference's `.half()` inputs (llm_trainer.py:366)
+    MK_LAUNCH((fill_kernel<_Float16>), dim3(ew_grid(n)), dim3(256), 0, MK_ST, (_Float16*)p, v, (long)n);
+    return mk_check_launch();
+  }
   MK_DISPATCH_T(dtype, MK_LAUNCH((fill_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, MK_ST,
                                           (T*)p, v, (long)n));
   return mk_check_launch();

@@ -112,12 +112,14 @@ class LlamaLayerFn(torch.autograd.Function):
     the weight gradients are returned as row slices of the fused gradient."""
 
     @staticmethod
-    def forward(ctx, x, kmask, pos, cos, sin, n_heads, eps, wq, wk, wv, wo, wg, wu, wd, ln1, ln2,
-                wqkv=None, wgu=None):
-        B, S, D = x.shape
-        M, H, hd = B * S, n_heads, D // n_heads
+    def _fwd(x2, B, S, kmask, pos, cos, sin, n_heads, eps, wq, wk, wv, wo, wg, wu, wd, ln1, ln2, wqkv,
+             wgu, grad_mode):
+        """the layer's forward on [M, D] rows; returns (out, intermediates the backward needs).
+        Deterministic (fixed reduction orders everywhere), so calling it again in the backward
+        of a checkpointed layer reproduces the intermediates bit for bit."""
+        M, D = x2.shape
+        H, hd = n_heads, D // n_heads
         FF = wg.shape[0]
-        x2 = _c2(x, M, D)
         _, y1, rstd1 = ops.rmsnorm_fwd(x2, ln1, eps)
         if wqkv is not None:
             qkv = ops.linear_fwd(y1, wqkv)                    # [M, 3D]
@@ -125,16 +127,15 @@ class LlamaLayerFn(torch.autograd.Function):
             ldq = 3 * D
         else:
             q, k, v = ops.linear_fwd(y1, wq), ops.linear_fwd(y1, wk), ops.linear_fwd(y1, wv)
-            qkv, ldq = None, D
+            ldq = D
         ops.rope_(q, cos, sin, pos, H, hd)
         ops.rope_(k, cos, sin, pos, H, hd)
-        att = torch.empty((M, D), dtype=x.dtype, device=x.device)
-        grad_mode = any(ctx.needs_input_grad)
-        use_flash = flash_ok(x.dtype, hd)
+        att = torch.empty((M, D), dtype=x2.dtype, device=x2.device)
+        use_flash = flash_ok(x2.dtype, hd)
         if use_flash:
             # fused attention: the S x S scores never reach HBM; training keeps only the
             # per-row log-sum-exp and recomputes P in the fused backward
-            lse = torch.empty((B, H, S), dtype=torch.float32, device=x.device) if grad_mode else None
+            lse = torch.empty((B, H, S), dtype=torch.float32, device=x2.device) if grad_mode else None
             ops.flash_attn_fwd(q, k, v, att, B, H, S, S, hd, ldq, S * ldq, ldq, S * ldq, ldq, S * ldq,
                                D, S * D, 1.0 / math.sqrt(hd), kmask=kmask, causal=True, lse=lse)
             probs = lse
@@ -153,10 +154,29 @@ class LlamaLayerFn(torch.autograd.Function):
             a = ops.swiglu_fwd(g, u)
             gu = None
         out = ops.linear_fwd(a, wd, residual=h1)
+        return out, (rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, gu, a), use_flash
+
+    @staticmethod
+    def forward(ctx, x, kmask, pos, cos, sin, n_heads, eps, wq, wk, wv, wo, wg, wu, wd, ln1, ln2,
+                wqkv=None, wgu=None, recompute=False):
+        """recompute=True is activation checkpointing (modeling.py:474-489): only the layer
+        input is kept and the backward re-runs `_fwd` first (identical results, ~13 fewer saved
+        [M, *] tensors per layer)."""
+        B, S, D = x.shape
+        M, H, hd = B * S, n_heads, D // n_heads
+        x2 = _c2(x, M, D)
+        grad_mode = any(ctx.needs_input_grad)
+        out, inter, use_flash = LlamaLayerFn._fwd(x2, B, S, kmask, pos, cos, sin, n_heads, eps, wq, wk,
+                                                  wv, wo, wg, wu, wd, ln1, ln2, wqkv, wgu,
+                                                  grad_mode and not recompute)
         if grad_mode:
-            ctx.save_for_backward(x2, rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, gu, a, pos,
-                                  cos, sin, wq, wk, wv, wo, wg, wu, wd, ln1, ln2, kmask, wqkv, wgu)
-            ctx.dims = (B, S, D, H, hd, use_flash, FF)
+            ctx.recompute = bool(recompute)
+            ctx.n_heads, ctx.eps = n_heads, eps
+            if recompute:
+                inter = (None,) * len(inter)
+            ctx.save_for_backward(x2, *inter, pos, cos, sin, wq, wk, wv, wo, wg, wu, wd, ln1, ln2,
+                                  kmask, wqkv, wgu)
+            ctx.dims = (B, S, D, H, hd, use_flash, wg.shape[0])
         return out.view(B, S, D)
 
     @staticmethod
@@ -165,6 +185,10 @@ class LlamaLayerFn(torch.autograd.Function):
          wo, wg, wu, wd, ln1, ln2, kmask, wqkv, wgu) = ctx.saved_tensors
         B, S, D, H, hd, use_flash, FF = ctx.dims
         M = B * S
+        if ctx.recompute:
+            _, (rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, gu, a), _ = LlamaLayerFn._fwd(
+                x2, B, S, kmask, pos, cos, sin, ctx.n_heads, ctx.eps, wq, wk, wv, wo, wg, wu, wd, ln1,
+                ln2, wqkv, wgu, True)
         need = ctx.needs_input_grad
         dout2 = _c2(dout, M, D)
         # ---- MLP
@@ -223,7 +247,7 @@ class LlamaLayerFn(torch.autograd.Function):
             dwv = ops.linear_dw(dv, y1) if need[9] else None
         dx, dln1 = ops.rmsnorm_bwd(dy1, x2, ln1, rstd1, dres=dh1)
         return (dx.view(B, S, D), None, None, None, None, None, None, dwq, dwk, dwv, dwo, dwg, dwu,
-                dwd, dln1 if need[14] else None, dln2 if need[15] else None, None, None)
+                dwd, dln1 if need[14] else None, dln2 if need[15] else None, None, None, None)
 
 
 def llama_layer_cached(x2, B, Sn, t0, kc, vc, Tmax, pos, cos, sin, n_heads, eps, wq, wk, wv, wo, wg, wu,

@@ -146,8 +146,10 @@ class LlamaDecoderLayer(nn.Module):
         except RuntimeError:   # not inside one storage
             return None
 
-    def forward(self, hidden_states, kmask=None, pos=None, past_key_value=None, use_cache=False):
-        """hidden_states [B,S,D]; kmask int32 [B,S] (0 = padding) or None; pos int32 [B*S]."""
+    def forward(self, hidden_states, kmask=None, pos=None, past_key_value=None, use_cache=False,
+                recompute=False):
+        """hidden_states [B,S,D]; kmask int32 [B,S] (0 = padding) or None; pos int32 [B*S];
+        recompute = activation checkpointing for this layer."""
         if past_key_value is not None or use_cache:
             raise NotImplementedError("KV-cache decode goes through LlamaForCausalLM.generate")
         a, m = self.self_attn, self.mlp
@@ -159,7 +161,7 @@ class LlamaDecoderLayer(nn.Module):
             hidden_states, kmask, pos, cos, sin, a.num_heads, self.input_layernorm.variance_epsilon,
             a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.o_proj.weight, m.gate_proj.weight,
             m.up_proj.weight, m.down_proj.weight, self.input_layernorm.weight,
-            self.post_attention_layernorm.weight, wqkv, wgu)
+            self.post_attention_layernorm.weight, wqkv, wgu, recompute)
         return (out,)
 
 
@@ -242,7 +244,9 @@ class LlamaModel(LlamaPreTrainedModel):
         for layer in self.layers:
             if output_hidden_states:
                 all_h += (h,)
-            h = layer(h, kmask=kmask, pos=pos)[0]
+            # modeling.py:474-489: checkpoint every decoder layer when training with the flag on
+            h = layer(h, kmask=kmask, pos=pos,
+                      recompute=self.gradient_checkpointing and self.training)[0]
         # NOTE: the final RMSNorm is fused with lm_head in LlamaForCausalLM; standalone
         # LlamaModel.forward applies it here.
         if getattr(self, "_defer_final_norm", False):

@@ -106,6 +106,37 @@ def test_train_mode_dropout_and_text_only(dev):
     assert out.logits.shape[1] == inp["input_ids"].shape[1] and torch.isfinite(out.loss)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fuse", [False, True])
+def test_gradient_checkpointing_is_bit_identical(dev, dtype, fuse):
+    """modeling.py:474-489 (checkpoint every decoder layer while training): our recompute path
+    re-runs the deterministic layer forward inside its backward, so loss, logits and every
+    gradient must equal the non-checkpointed run bit for bit."""
+    fx = load_case("micro_all")
+    cfg = configs.get(fx["config_name"])
+    model = build_model(cfg, fx["state"], dtype, dev, fuse=fuse)
+    llm = model.llm.train()
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(3, cfg["llama"]["vocab_size"], (3, 24), generator=g).to(dev)
+    am = torch.ones_like(ids)
+    am[1, 19:] = 0
+    res = []
+    for flag in (False, True):
+        llm.model.gradient_checkpointing = flag
+        llm.zero_grad(set_to_none=True)
+        out = llm(input_ids=ids, attention_mask=am, labels=ids)
+        out.loss.backward()
+        res.append((out.loss.detach().clone(), out.logits.detach().clone(),
+                    {n: p.grad.clone() for n, p in llm.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert res[0][2].keys() == res[1][2].keys() and len(res[0][2]) > 10
+    for n in res[0][2]:
+        assert torch.equal(res[0][2][n], res[1][2][n]), n
+    # eval mode ignores the flag (reference: `self.gradient_checkpointing and self.training`)
+    llm.eval()
+    assert torch.equal(llm(input_ids=ids, attention_mask=am).logits, res[0][1])
+
+
 @pytest.mark.parametrize("use_cache", [True, False])
 def test_generate_matches_restated_greedy(dev, use_cache):
     """greedy token ids bit-exact vs the restated HF greedy loop (golden), with the KV-cache
