@@ -545,12 +545,12 @@ MK_DEV int kswz(int row, int kc) {
   if constexpr (BKv == 64) return kc ^ ((row >> 1) & 7);
   else return kc ^ ((row >> 2) & 3);
 }
-template <bool RED_MAJOR, int BKv>
+template <bool RED_MAJOR, int BKv, int NWv>
 MK_DEV void v2_voffsets(int row0, int R, long ld, int w, int l, int (&voff)[4]) {
   constexpr int CR = BKv / 8;          // 16-B chunks per K-major row
 #pragma unroll
-  for (int i = 0; i < BKv / 16; ++i) {
-    const int p = w + 4 * i;
+  for (int i = 0; i < BKv / 4 / NWv; ++i) {
+    const int p = w + NWv * i;
     if constexpr (!RED_MAJOR) {
       const int row = p * (64 / CR) + l / CR;
       const int kc = kswz<BKv>(row, l % CR);
@@ -583,15 +583,22 @@ MK_DEV void v2_frag_offsets(int wrow0, int l, int (&off)[2][4]) {
     }
   }
 }
-template <bool A_RED, bool B_RED, int BKv>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
+// NWv = 4: waves 2 x 2 of 64 x 64 (2 x 2 fragments).  NWv = 8: waves 2 (M) x 4 (N) of 64 x 32
+// (2 x 1 fragments, 32 accumulator registers) -- the same tile and LDS image with twice the
+// waves per SIMD to hide LDS / barrier latency (the kernel is latency- not bandwidth-bound).
+template <bool A_RED, bool B_RED, int BKv, int NWv>
+MK_DEV void v2_body(const GemmArgs& g) {
   constexpr int TILE_B = 128 * BKv * 2;   // bytes per operand tile
-  constexpr int NP = BKv / 16;            // LDS-DMA pieces per wave per operand tile
+  constexpr int NP = BKv / 4 / NWv;       // LDS-DMA pieces per wave per operand tile
   constexpr int NKS = BKv / 16;           // MFMA k-steps per tile
+  constexpr int FN = NWv == 8 ? 1 : 2;    // N fragments per wave
+  constexpr int NT = NWv * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
   int piece = -1, tail_idx = 0, zlin = 0;
-  int kt_begin = 0, kt_end = g.K / BKv;
+  // K % BKv != 0 only reaches this kernel with BOTH operands reduction-major: rows >= K are
+  // then outside the buffer descriptors and load as zeros
+  int kt_begin = 0, kt_end = (g.K + BKv - 1) / BKv;
   {
     const int bid = blockIdx.x;
     int t;
@@ -620,7 +627,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
   const int m0 = tm * BM, n0 = tn * BN;
   const int l = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
+  const int wm0 = NWv == 8 ? (w >> 2) * 64 : (w >> 1) * 64;
+  const int wn0 = NWv == 8 ? (w & 3) * 32 : (w & 1) * 64;
 
   // buffer descriptors (tile-relative bases keep voffset small; num_records bounds the
   // reduction-major over-read of the last K row)
@@ -635,19 +643,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
       (void*)bbase, 0, (int)min(b_bytes, 0x7fffffffL), 0x00020000);
   int voffA[4], voffB[4];
-  v2_voffsets<A_RED, BKv>(m0, g.M, g.lda, w, l, voffA);
-  v2_voffsets<B_RED, BKv>(n0, g.N, g.ldb, w, l, voffB);
+  v2_voffsets<A_RED, BKv, NWv>(m0, g.M, g.lda, w, l, voffA);
+  v2_voffsets<B_RED, BKv, NWv>(n0, g.N, g.ldb, w, l, voffB);
   const int stepA = A_RED ? (int)(BKv * g.lda * 2) : BKv * 2;  // bytes per K-tile
   const int stepB = B_RED ? (int)(BKv * g.ldb * 2) : BKv * 2;
   int offA[2][4], offB[2][4];
   v2_frag_offsets<A_RED, BKv>(wm0, l, offA);
   v2_frag_offsets<B_RED, BKv>(wn0, l, offB);
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][FN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -657,12 +665,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < NP; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsA, (__attribute__((address_space(3))) void*)(la + i * 4096), 16, voffA[i], sA, 0, 0);
+          rsA, (__attribute__((address_space(3))) void*)(la + i * (NWv * 1024)), 16, voffA[i], sA, 0, 0);
 #pragma unroll
     for (int i = 0; i < NP; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsB, (__attribute__((address_space(3))) void*)(la + TILE_B + i * 4096), 16, voffB[i],
-          sB, 0, 0);
+          rsB, (__attribute__((address_space(3))) void*)(la + TILE_B + i * (NWv * 1024)), 16,
+          voffB[i], sB, 0, 0);
     sA += stepA;
     sB += stepB;
   };
@@ -686,15 +694,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
     DST[0] = MK_V2_FRAG(A_RED, offA, 0, KS, (STAGE) * 2 * TILE_B);                           \
     DST[1] = MK_V2_FRAG(A_RED, offA, 1, KS, (STAGE) * 2 * TILE_B);                           \
     DST[2] = MK_V2_FRAG(B_RED, offB, 0, KS, (STAGE) * 2 * TILE_B + TILE_B);              \
-    DST[3] = MK_V2_FRAG(B_RED, offB, 1, KS, (STAGE) * 2 * TILE_B + TILE_B);              \
+    if constexpr (FN == 2) DST[3] = MK_V2_FRAG(B_RED, offB, 1, KS, (STAGE) * 2 * TILE_B + TILE_B); \
   } while (0)
 #define MK_V2_MFMA4(F)                                                                           \
   do {                                                                                           \
     __builtin_amdgcn_s_setprio(1);                                                               \
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[2], F[0], acc[0][0], 0, 0, 0);         \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[3], F[0], acc[0][1], 0, 0, 0);         \
+    if constexpr (FN == 2)                                                                       \
+      acc[0][FN - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[3], F[0], acc[0][FN - 1], 0, 0, 0); \
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[2], F[1], acc[1][0], 0, 0, 0);         \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[3], F[1], acc[1][1], 0, 0, 0);         \
+    if constexpr (FN == 2)                                                                       \
+      acc[1][FN - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[3], F[1], acc[1][FN - 1], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                               \
   } while (0)
 // fragments of k-step ks+1 are requested before the MFMAs of k-step ks (two register sets)
@@ -756,14 +766,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < FN; ++j)
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-          const int e = (i * 2 + j) * 4 + q4;
+          const int e = (i * FN + j) * 4 + q4;
           u32x4 v;
           v[0] = __float_as_uint(acc[i][j][4 * q4]); v[1] = __float_as_uint(acc[i][j][4 * q4 + 1]);
           v[2] = __float_as_uint(acc[i][j][4 * q4 + 2]); v[3] = __float_as_uint(acc[i][j][4 * q4 + 3]);
-          __builtin_amdgcn_raw_buffer_store_b128(v, rsS, (e * 256 + (int)threadIdx.x) * 16, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsS, (e * NT + (int)threadIdx.x) * 16, 0, 16);
         }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -781,7 +791,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < FN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     for (int pc = 0; pc < g.split; ++pc) {
@@ -789,17 +799,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
-            const int e = (i * 2 + j) * 4 + q4;
-            const float4 v = *reinterpret_cast<const float4*>(sl + ((long)e * 256 + threadIdx.x) * 4);
+            const int e = (i * FN + j) * 4 + q4;
+            const float4 v = *reinterpret_cast<const float4*>(sl + ((long)e * NT + threadIdx.x) * 4);
             acc[i][j][4 * q4] += v.x; acc[i][j][4 * q4 + 1] += v.y;
             acc[i][j][4 * q4 + 2] += v.z; acc[i][j][4 * q4 + 3] += v.w;
           }
     }
   }
   wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0);
+}
+template <bool A_RED, bool B_RED, int BKv>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
+  v2_body<A_RED, B_RED, BKv, 4>(g);
+}
+template <bool A_RED, bool B_RED>
+__global__ __launch_bounds__(512, 4) void gemm_bf16_v4_kernel(GemmArgs g) {
+  v2_body<A_RED, B_RED, 64, 8>(g);
 }
 
 // ------------------------------------------------ v3: 256x256 tile, 8 waves of 128x64 --
@@ -1267,14 +1285,16 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
     };
     const bool v2_ok = aligned16(d->A) && aligned16(d->B) && (d->lda % 8 == 0) && (d->ldb % 8 == 0) &&
                        (d->sA1 % 8 == 0) && (d->sA2 % 8 == 0) && (d->sB1 % 8 == 0) &&
-                       (d->sB2 % 8 == 0) && (d->K % BK == 0) &&
+                       (d->sB2 % 8 == 0) &&
+                       (d->K % BK == 0 || (d->a_red_major && d->b_red_major && d->K > BK)) &&
                        fits(d->a_red_major, d->lda, BM) && fits(d->b_red_major, d->ldb, BN);
     if (cfg == 6) {  // 256x256 tiles only pay for big problems; otherwise the 128x128 v2 kernel
       const bool big = d->M >= 512 && d->N >= 512 && d->K >= 512 && nbatch == 1 && d->ws &&
                        fits(d->a_red_major, d->lda, 256) && fits(d->b_red_major, d->ldb, 256);
       if (!big) cfg = 5;
     }
-    if ((cfg == 5 || cfg == 6 || cfg == 7) && !v2_ok) cfg = 0;
+    if (cfg == 6 && d->K % BK) cfg = 5;   // only the v2 body handles a reduction tail
+    if ((cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8) && !v2_ok) cfg = 0;
     // Measured (profiles/): with BOTH operands reduction-major (dW = dy^T x) the global rows are
     // whole 256-B lines whatever BK is, and BK = 32 (32 KiB LDS -> 4 workgroups per CU) is 17 %
     // faster (1090-1140 vs 930-980 TFLOP/s); K-major operands would degrade to 64-B segments.
@@ -1303,14 +1323,14 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
     g.counters = nullptr;
     static const int ablate = [] { const char* e = getenv("MK_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     g.ablate = ablate;
-    if ((cfg == 5 || cfg == 7 || (cfg == 6 && nbatch == 1)) && d->ws && !getenv("MK_GEMM_NO_STREAMK")) {
+    if ((cfg == 5 || cfg == 7 || cfg == 8 || (cfg == 6 && nbatch == 1)) && d->ws && !getenv("MK_GEMM_NO_STREAMK")) {
       static const int slots = [] {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return cus;
       }() * (cfg == 6 ? 1 : (cfg == 7 ? 4 : 2));  // resident workgroups per CU
-      const int T = g.tiles_m * g.tiles_n * nbatch, nkt = d->K / bkv;
+      const int T = g.tiles_m * g.tiles_n * nbatch, nkt = (d->K + bkv - 1) / bkv;
       const int R = T % slots;
       int sp = R > 0 ? slots / R : 1;
       if (sp > nkt / 2) sp = nkt / 2;  // at least two K-tiles per piece
@@ -1365,6 +1385,16 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
   } while (0)
 #define MK_V2S(AR, BR)                                                                        \
   MK_LAUNCH((gemm_bf16_v2_kernel<AR, BR, 32>), grid, dim3(256), 2 * TILE_BYTES, st, g)
+#define MK_V4(AR, BR)                                                                         \
+  do {                                                                                        \
+    static bool attr_done = false;                                                            \
+    if (!attr_done) {                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v4_kernel<AR, BR>),  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);  \
+      attr_done = true;                                                                       \
+    }                                                                                         \
+    MK_LAUNCH((gemm_bf16_v4_kernel<AR, BR>), grid, dim3(512), 4 * TILE_BYTES, st, g);         \
+  } while (0)
 #define MK_V3(AR, BR)                                                                         \
   do {                                                                                        \
     static bool attr_done = false;                                                            \
@@ -1378,6 +1408,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
 #define MK_LAYOUT(AR, BR)                                    \
   do {                                                       \
     if (cfg == 7) MK_V2S(AR, BR);                            \
+    else if (cfg == 8) MK_V4(AR, BR);                        \
     else if (cfg == 6) MK_V3(AR, BR);                        \
     else if (cfg == 5) MK_V2(AR, BR);                        \
     else if (cfg == 0) MK_REG(AR, BR);                       \
@@ -1393,6 +1424,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
 #undef MK_LAYOUT
 #undef MK_V2
 #undef MK_V2S
+#undef MK_V4
 #undef MK_V3
 #undef MK_REG
 #undef MK_PIPE

@@ -176,3 +176,52 @@ def test_fused_attention_matches_gemm_softmax_path_at_seq_2048(dev):
     eng.attention_bwd(d(do), d(q), d(k), d(v), probs, None, d(dq2), d(dk2), d(dv2), B, Hh, Sq, Sq, hd, scale)
     for a, b_ in ((dq, dq2), (dk, dk2), (dv, dv2)):
         assert (a.float() - b_.float()).abs().max().item() < 3e-2 * b_.float().abs().max().item() + 2e-3
+
+
+def _rel(got, ref):
+    d = (got.float().cpu() - ref).abs()
+    return d.max().item() / ref.abs().max().item(), d.mean().item() / ref.abs().mean().item()
+
+
+def test_real_dimension_encoders_and_prefix_vs_oracle(dev):
+    """BASELINE cfg 4 geometry at the REAL tower dimensions: CLIP ViT-L/14 (24 layers, 257
+    tokens) on 1 image + 6 video frames, Whisper-base (6 layers, 1500 frames), the video
+    self-attention, Conv1d/Linear projections and the three alignment attentions at D = 4096,
+    spliced into the LLaMA input -- bf16 engine vs the fp32 CPU oracle on the same (bf16-exact)
+    random weights.  Only the LLaMA stack is cut (1 layer, 2,048-token text vocabulary) so the
+    CPU oracle finishes in seconds; its real-size pieces are the tests above.
+    Tolerance: every activation is stored in bf16 (2^-8 relative); 24 + 6 pre-LN residual layers
+    keep the relative error of the features at a few 1e-3 on average and < 5 % of the largest
+    magnitude at the worst element (stated per assert; integer outputs bit-exact)."""
+    from macaw_llm_amd.factory import baseline_config, build_model
+    from oracle import inputs as oin
+    cfg = baseline_config("real_7b")
+    cfg["llama"].update(num_hidden_layers=1, vocab_size=2055)
+    cfg["tags"] = dict(image=(2048, 2049), audio=(2050, 2051), video=(2052, 2053), pad=2054)
+    model = build_model(cfg, dtype=torch.bfloat16, device=dev, seed=7).eval()
+    sd = restate.hot_path_state({k: v.detach().float().cpu() for k, v in model.state_dict().items()})
+    inp = oin.make_inputs(cfg, batch=1, text_len=24, seed=3, pad_tail=0, n_prompt=8)
+    inp = {k: (_bf(v).float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}
+    with torch.no_grad():
+        ref = restate.mm_forward(sd, inp, cfg)
+        dinp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+        dinp = {k: (_bf(v) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in dinp.items()}
+        img_f = model.encode_image(dinp["images"])
+        aud_f = model.encode_audio(dinp["audios"])
+        vid_f = model.encode_video_long(dinp["videos"])
+        emb, am, lab = model.prepare_inputs_for_generation(dinp)
+        out = model(inputs=dinp)
+    assert tuple(img_f.shape) == (1, 256, 768) and tuple(aud_f.shape) == (1, 1500, 512)
+    assert tuple(vid_f.shape) == (1, 6 * 256, 768)
+    errs = {}
+    for name, got, want in (("image", img_f, ref["image_features"]), ("audio", aud_f, ref["audio_features"]),
+                            ("video", vid_f, ref["video_features"]), ("inputs_embeds", emb, ref["inputs_embeds"]),
+                            ("logits", out.logits, ref["logits"])):
+        errs[name] = _rel(got, want)
+    print("real-dimension relative errors (max/max, mean/mean):", errs)
+    S = 24 + 3 * 2 + 6 + 6 + 51                    # text + tags + image/audio/video prefix tokens
+    assert emb.shape[1] == S == ref["inputs_embeds"].shape[1]
+    assert torch.equal(am.cpu(), ref["attention_mask"]) and torch.equal(lab.cpu(), ref["labels"])
+    for name, (emax, emean) in errs.items():
+        assert emax <= 5e-2 and emean <= 2e-2, (name, emax, emean)
+    assert abs(out.loss.item() - ref["loss"].item()) <= 2e-2 * max(1.0, abs(ref["loss"].item()))

@@ -138,3 +138,18 @@ def test_loads_a_checkpoint_written_by_the_reference(tmp_path):
     rs, ms = ref.state_dict(), mine.state_dict()
     assert set(rs) == set(ms)
     assert all(torch.equal(rs[k], ms[k]) for k in rs)
+
+
+def test_gradient_checkpointing_flag_surface():
+    """modeling.py:325-329,474: HF's enable/disable toggles LlamaModel.gradient_checkpointing,
+    which the layer loop turns into LlamaLayerFn(recompute=True) while training"""
+    from transformers import LlamaConfig
+    from macaw_llm_amd import modeling as M
+    cfg = LlamaConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                      vocab_size=100)
+    m = M.LlamaForCausalLM(cfg)
+    assert m.supports_gradient_checkpointing and m.model.gradient_checkpointing is False
+    m.gradient_checkpointing_enable()
+    assert m.model.gradient_checkpointing is True
+    m.gradient_checkpointing_disable()
+    assert m.model.gradient_checkpointing is False

@@ -40,7 +40,7 @@ DTYPES = [torch.float32, torch.bfloat16]
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("a_red,b_red", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 107, 72), (37, 250, 1000),
-                                   (6, 9, 4)])
+                                   (6, 9, 4), (256, 384, 1000), (136, 264, 2007)])
 def test_gemm_layouts(dev, dtype, a_red, b_red, M, N, K):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     A = _rand((K, M) if a_red else (M, K), dtype, g)
