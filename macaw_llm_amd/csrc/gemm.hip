@@ -820,6 +820,16 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_v4_kernel(GemmArgs g) {
   v2_body<A_RED, B_RED, 64, 8>(g);
 }
 
+// The compiler sometimes loses the wave-uniformity of a tile base pointer (then every
+// buffer_load ... lds becomes a 12-instruction waterfall loop over the descriptor): pin it.
+template <typename T>
+MK_DEV const T* uniform_ptr(const T* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<const T*>(((uint64_t)hi << 32) | lo);
+}
+
 // ------------------------------------------------ v3: 256x256 tile, 8 waves of 128x64 --
 // Same issue-lean structure as v2 with twice the MFMA work per barrier and per LDS byte:
 // 8 waves (2 M x 4 N), wave tile 128x64 = 4x2 fragments (128 accumulator registers), LDS
@@ -864,8 +874,23 @@ MK_DEV void v3_frag_offsets(int wrow0, int l, int (&off)[NF][4]) {
   }
 }
 
-template <bool A_RED, bool B_RED>
+// STAG = true ("v5"): the two M-halves of the workgroup (waves 0-3 / 4-7, one of each per SIMD)
+// run ONE BARRIER out of phase, at k-step granularity: while one group issues the six
+// ds_read_b128 of its next k-step (and its share of the next tile's LDS-DMA), the other group
+// owns the matrix pipe with its 8 MFMAs.  Lock-step waves (STAG = false) all burst-read 48 KiB
+// of LDS together after each barrier while the MFMA pipe idles, then all contend for it.
+// Hazards by construction: a tile's LDS-DMA is issued >= 1 barrier after every wave retired
+// (lgkmcnt) its reads of that stage, every wave drains vmcnt in the interval BEFORE the barrier
+// that precedes the first read of the new tile, and the loads have >= 3 intervals to land.
+// SCHED = 2 ("v6"): same stagger, but the A operand has THREE 32-KiB LDS slots and B two
+// (160 KiB): A is prefetched two tiles ahead, so the eight LDS-DMA instructions a wave issues per
+// tile are spread two per k-step over ALL four k-steps (an LDS-DMA issue costs the wave 60-180
+// cycles; four in one k-step made that step twice as long as the MFMA group it has to hide
+// under) and still have >= 3 barrier intervals to land; the end-of-tile wait is a counted
+// vmcnt(2) that leaves the just-issued A pieces in flight.
+template <bool A_RED, bool B_RED, int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g) {
+  constexpr bool STAG = SCHED == 1;
   constexpr int BM3 = 256, BN3 = 256, FM = 4, FN = 2;
   constexpr int A_BYTES = BM3 * 128, STAGE = 2 * A_BYTES;  // 64 KiB per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -895,8 +920,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm0 = (w >> 2) * 128, wn0 = (w & 3) * 64;
 
-  const bf16* abase = A_RED ? A + m0 : A + (long)m0 * g.lda;
-  const bf16* bbase = B_RED ? B + n0 : B + (long)n0 * g.ldb;
+  const bf16* abase = uniform_ptr(A_RED ? A + m0 : A + (long)m0 * g.lda);
+  const bf16* bbase = uniform_ptr(B_RED ? B + n0 : B + (long)n0 * g.ldb);
   const long a_bytes = A_RED ? ((long)(g.K - 1) * g.lda + (g.M - m0)) * 2
                              : ((long)(min(g.M - m0, BM3) - 1) * g.lda + g.K) * 2;
   const long b_bytes = B_RED ? ((long)(g.K - 1) * g.ldb + (g.N - n0)) * 2
@@ -995,6 +1020,143 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g) {
   } while (0)
 
   const int nk = kt_end - kt_begin;
+  if constexpr (SCHED == 2) {
+    constexpr int B_BASE = 3 * A_BYTES;
+    const int grp = w >> 2;
+    int gA = kt_begin * stepA, gB = kt_begin * stepB;   // global byte offsets of the next A / B tile to load
+    auto load_a = [&](int slot, int i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsA, (__attribute__((address_space(3))) void*)(smem + slot * A_BYTES + w * 1024 + i * 8192), 16,
+          voffA[i], gA, 0, 0);
+    };
+    auto load_b = [&](int slot, int i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsB, (__attribute__((address_space(3))) void*)(smem + B_BASE + slot * A_BYTES + w * 1024 + i * 8192),
+          16, voffB[i], gB, 0, 0);
+    };
+#define MK_V6_BAR()                            \
+  do {                                         \
+    __builtin_amdgcn_sched_barrier(0);         \
+    __builtin_amdgcn_s_barrier();              \
+    __builtin_amdgcn_sched_barrier(0);         \
+  } while (0)
+    // prologue: A(0), B(0), A(1)
+    if (nk > 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) load_a(0, i);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) load_b(0, i);
+      gA += stepA; gB += stepB;
+      if (nk > 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_a(1, i);
+        gA += stepA;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MK_V6_BAR();
+    if (grp == 1) MK_V6_BAR();
+    int sa = 0, sb = 0;        // slots of the tile being computed
+    int sa2 = 2, sb1 = 1;      // slots the prefetches of this tile go to: A(t+2), B(t+1)
+#define MK_V6_STEP(KS)                                                                           \
+  do {                                                                                           \
+    bf16x8 fr_[6];                                                                               \
+    fr_[0] = MK_V3_FRAG(A_RED, offA, 0, KS, abase_lds);                                          \
+    fr_[1] = MK_V3_FRAG(A_RED, offA, 1, KS, abase_lds);                                          \
+    fr_[2] = MK_V3_FRAG(A_RED, offA, 2, KS, abase_lds);                                          \
+    fr_[3] = MK_V3_FRAG(A_RED, offA, 3, KS, abase_lds);                                          \
+    fr_[4] = MK_V3_FRAG(B_RED, offB, 0, KS, bbase_lds);                                          \
+    fr_[5] = MK_V3_FRAG(B_RED, offB, 1, KS, bbase_lds);                                          \
+    if (grp == 0) {                                                                              \
+      if ((KS) == 0 && has_a) { load_a(sa2, 0); load_a(sa2, 1); }                                \
+      if ((KS) == 1 && has_b) { load_b(sb1, 0); load_b(sb1, 1); }                                \
+      if ((KS) == 2 && has_b) { load_b(sb1, 2); load_b(sb1, 3); }                                \
+      if ((KS) == 3 && has_a) { load_a(sa2, 2); load_a(sa2, 3); }                                \
+    } else {                                                                                     \
+      if ((KS) == 0 && has_b) { load_b(sb1, 0); load_b(sb1, 1); }                                \
+      if ((KS) == 1 && has_b) { load_b(sb1, 2); load_b(sb1, 3); }                                \
+      if ((KS) == 2 && has_a) { load_a(sa2, 0); load_a(sa2, 1); }                                \
+      if ((KS) == 3 && has_a) { load_a(sa2, 2); load_a(sa2, 3); }                                \
+      if ((KS) == 3) {                                                                           \
+        if (has_a) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                              \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
+      }                                                                                          \
+    }                                                                                            \
+    MK_V6_BAR();                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                               \
+    MK_V3_MFMA(fr_);                                                                             \
+    __builtin_amdgcn_s_setprio(0);                                                               \
+    if (grp == 0 && (KS) == 3) {                                                                 \
+      if (has_a) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+    }                                                                                            \
+    MK_V6_BAR();                                                                                 \
+  } while (0)
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool has_b = kt + 1 < nk, has_a = kt + 2 < nk;
+      const int abase_lds = sa * A_BYTES, bbase_lds = B_BASE + sb * A_BYTES;
+      MK_V6_STEP(0);
+      MK_V6_STEP(1);
+      MK_V6_STEP(2);
+      MK_V6_STEP(3);
+      gA += stepA; gB += stepB;
+      sa = sa == 2 ? 0 : sa + 1;
+      sa2 = sa2 == 2 ? 0 : sa2 + 1;
+      sb ^= 1; sb1 ^= 1;
+    }
+    if (grp == 0) MK_V6_BAR();
+#undef MK_V6_STEP
+#undef MK_V6_BAR
+  } else if constexpr (STAG) {
+    if (nk > 0) issue(0);
+#define MK_V5_BAR()                            \
+  do {                                         \
+    __builtin_amdgcn_sched_barrier(0);         \
+    __builtin_amdgcn_s_barrier();              \
+    __builtin_amdgcn_sched_barrier(0);         \
+  } while (0)
+// one k-step of one wave: L segment | barrier | M segment | barrier
+#define MK_V5_STEP(KS, STAGE_, NEXT_)                                                            \
+  do {                                                                                           \
+    bf16x8 fr_[6];                                                                               \
+    MK_V3_LOAD(fr_, KS, STAGE_);                                                                 \
+    if (NEXT_) {                                                                                 \
+      if (grp == 0 && (KS) == 1) { issue_part(1 - (STAGE_), 0); issue_part(1 - (STAGE_), 1); }   \
+      if (grp == 0 && (KS) == 2) { issue_part(1 - (STAGE_), 2); issue_part(1 - (STAGE_), 3); }   \
+      if (grp == 1 && (KS) == 0) { issue_part(1 - (STAGE_), 0); issue_part(1 - (STAGE_), 1); }   \
+      if (grp == 1 && (KS) == 1) { issue_part(1 - (STAGE_), 2); issue_part(1 - (STAGE_), 3); }   \
+    }                                                                                            \
+    if (grp == 1 && (KS) == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+    MK_V5_BAR();                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                               \
+    MK_V3_MFMA(fr_);                                                                             \
+    __builtin_amdgcn_s_setprio(0);                                                               \
+    if (grp == 0 && (KS) == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  \
+    MK_V5_BAR();                                                                                 \
+  } while (0)
+#define MK_V5_TILE(STAGE_, NEXT_)    \
+  do {                               \
+    MK_V5_STEP(0, STAGE_, NEXT_);    \
+    MK_V5_STEP(1, STAGE_, NEXT_);    \
+    MK_V5_STEP(2, STAGE_, NEXT_);    \
+    MK_V5_STEP(3, STAGE_, NEXT_);    \
+  } while (0)
+    const int grp = w >> 2;  // wave-uniform (SGPR): M half of the tile = stagger group
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MK_V5_BAR();             // tile 0 landed and visible
+    if (grp == 1) MK_V5_BAR();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      MK_V5_TILE(0, true);
+      MK_V5_TILE(1, kt + 2 < nk);
+    }
+    if (kt < nk) MK_V5_TILE(0, false);
+    if (grp == 0) MK_V5_BAR();
+#undef MK_V5_TILE
+#undef MK_V5_STEP
+#undef MK_V5_BAR
+  } else {
   if (nk > 0) issue(0);
   int kt = 0;
   for (; kt + 1 < nk; kt += 2) {
@@ -1006,6 +1168,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g) {
   if (kt < nk) {
     MK_V3_SYNC();
     MK_V3_COMPUTE(0, false);
+  }
   }
 #undef MK_V3_SYNC
 #undef MK_V3_COMPUTE
@@ -1288,22 +1451,23 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
                        (d->sB2 % 8 == 0) &&
                        (d->K % BK == 0 || (d->a_red_major && d->b_red_major && d->K > BK)) &&
                        fits(d->a_red_major, d->lda, BM) && fits(d->b_red_major, d->ldb, BN);
-    if (cfg == 6) {  // 256x256 tiles only pay for big problems; otherwise the 128x128 v2 kernel
+    if (cfg == 6 || cfg == 9 || cfg == 10) {  // 256x256 tiles only pay for big problems; otherwise the 128x128 v2 kernel
       const bool big = d->M >= 512 && d->N >= 512 && d->K >= 512 && nbatch == 1 && d->ws &&
                        fits(d->a_red_major, d->lda, 256) && fits(d->b_red_major, d->ldb, 256);
       if (!big) cfg = 5;
     }
-    if (cfg == 6 && d->K % BK) cfg = 5;   // only the v2 body handles a reduction tail
-    if ((cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8) && !v2_ok) cfg = 0;
+    if ((cfg == 6 || cfg == 9 || cfg == 10) && d->K % BK) cfg = 5;   // only the v2 body handles a reduction tail
+    if (cfg >= 5 && !v2_ok) cfg = 0;
     // Measured (profiles/): with BOTH operands reduction-major (dW = dy^T x) the global rows are
     // whole 256-B lines whatever BK is, and BK = 32 (32 KiB LDS -> 4 workgroups per CU) is 17 %
     // faster (1090-1140 vs 930-980 TFLOP/s); K-major operands would degrade to 64-B segments.
     if (cfg == 5 && d->a_red_major && d->b_red_major && !getenv("MK_GEMM_NO_BK32")) cfg = 7;
     const int bkv = cfg == 7 ? 32 : BK;
     rec.cfg = cfg;
-    if (cfg >= 3 && cfg != 5 && (d->M <= 128 || (long)mk_cdiv(d->M, 256) * mk_cdiv(d->N, BN) * nbatch < 256)) cfg -= 2;
-    const int bm = (cfg == 3 || cfg == 4 || cfg == 6) ? 256 : 128;
-    const int bn = cfg == 6 ? 256 : BN;
+    if ((cfg == 3 || cfg == 4) && (d->M <= 128 || (long)mk_cdiv(d->M, 256) * mk_cdiv(d->N, BN) * nbatch < 256)) cfg -= 2;
+    const bool t256 = cfg == 6 || cfg == 9 || cfg == 10;
+    const int bm = (cfg == 3 || cfg == 4 || t256) ? 256 : 128;
+    const int bn = t256 ? 256 : BN;
     const int stages = (cfg == 2 || cfg == 4) ? 3 : 2;
     g.tiles_m = mk_cdiv(d->M, bm);
     g.tiles_n = mk_cdiv(d->N, bn);
@@ -1323,19 +1487,19 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
     g.counters = nullptr;
     static const int ablate = [] { const char* e = getenv("MK_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     g.ablate = ablate;
-    if ((cfg == 5 || cfg == 7 || cfg == 8 || (cfg == 6 && nbatch == 1)) && d->ws && !getenv("MK_GEMM_NO_STREAMK")) {
+    if ((cfg == 5 || cfg == 7 || cfg == 8 || (t256 && nbatch == 1)) && d->ws && !getenv("MK_GEMM_NO_STREAMK")) {
       static const int slots = [] {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return cus;
-      }() * (cfg == 6 ? 1 : (cfg == 7 ? 4 : 2));  // resident workgroups per CU
+      }() * (t256 ? 1 : (cfg == 7 ? 4 : 2));  // resident workgroups per CU
       const int T = g.tiles_m * g.tiles_n * nbatch, nkt = (d->K + bkv - 1) / bkv;
       const int R = T % slots;
       int sp = R > 0 ? slots / R : 1;
       if (sp > nkt / 2) sp = nkt / 2;  // at least two K-tiles per piece
       if (sp > 64) sp = 64;
-      const long need = 4096 + (long)R * sp * (cfg == 6 ? 128 * 512 : 64 * 256) * 4;
+      const long need = 4096 + (long)R * sp * (t256 ? 128 * 512 : 64 * 256) * 4;
       if (R > 0 && sp >= 2 && need <= d->ws_bytes) {
         g.dp_tiles = T - R;
         g.split = sp;
@@ -1399,17 +1563,39 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
   do {                                                                                        \
     static bool attr_done = false;                                                            \
     if (!attr_done) {                                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v3_kernel<AR, BR>),  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v3_kernel<AR, BR, 0>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 131072);          \
       attr_done = true;                                                                       \
     }                                                                                         \
-    MK_LAUNCH((gemm_bf16_v3_kernel<AR, BR>), grid, dim3(512), 131072, st, g);                 \
+    MK_LAUNCH((gemm_bf16_v3_kernel<AR, BR, 0>), grid, dim3(512), 131072, st, g);          \
+  } while (0)
+#define MK_V5(AR, BR)                                                                         \
+  do {                                                                                        \
+    static bool attr_done = false;                                                            \
+    if (!attr_done) {                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v3_kernel<AR, BR, 1>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 131072);          \
+      attr_done = true;                                                                       \
+    }                                                                                         \
+    MK_LAUNCH((gemm_bf16_v3_kernel<AR, BR, 1>), grid, dim3(512), 131072, st, g);           \
+  } while (0)
+#define MK_V6(AR, BR)                                                                         \
+  do {                                                                                        \
+    static bool attr_done = false;                                                            \
+    if (!attr_done) {                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v3_kernel<AR, BR, 2>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 163840);          \
+      attr_done = true;                                                                       \
+    }                                                                                         \
+    MK_LAUNCH((gemm_bf16_v3_kernel<AR, BR, 2>), grid, dim3(512), 163840, st, g);              \
   } while (0)
 #define MK_LAYOUT(AR, BR)                                    \
   do {                                                       \
     if (cfg == 7) MK_V2S(AR, BR);                            \
     else if (cfg == 8) MK_V4(AR, BR);                        \
     else if (cfg == 6) MK_V3(AR, BR);                        \
+    else if (cfg == 9) MK_V5(AR, BR);                        \
+    else if (cfg == 10) MK_V6(AR, BR);                       \
     else if (cfg == 5) MK_V2(AR, BR);                        \
     else if (cfg == 0) MK_REG(AR, BR);                       \
     else if (cfg == 1) MK_PIPE(AR, BR, 128, 2);              \
@@ -1426,6 +1612,8 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
 #undef MK_V2S
 #undef MK_V4
 #undef MK_V3
+#undef MK_V5
+#undef MK_V6
 #undef MK_REG
 #undef MK_PIPE
   } else {
