@@ -188,8 +188,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+    force_coll = bool(os.environ.get("MACAW_FORCE_COLLECTIVES"))   # 1-rank RCCL group: call-path check
+    if world > 1 or force_coll:
+        if force_coll and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from macaw_llm_amd import ops
     from macaw_llm_amd.train import OverlappedStep
@@ -203,7 +209,9 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     opt = FusedAdamW(params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
     runtime = OverlappedStep(params, opt, overlap=not os.environ.get("MACAW_NO_OVERLAP"),
-                             overlap_optimizer=bool(os.environ.get("MACAW_OVERLAP_ADAMW")))
+                             overlap_optimizer=bool(os.environ.get("MACAW_OVERLAP_ADAMW")),
+                             shard_optimizer=False if os.environ.get("MACAW_NO_SHARD") else None,
+                             force_collectives=force_coll)
     B = args.batch_per_gpu
     inputs = synthetic_inputs(cfg, B, TEXT_LEN, modalities=("images", "audios"), seed=1 + rank, device=dev)
 
@@ -257,7 +265,9 @@ def main():
                                     "audio + 128-token text (S=144), fwd+bwd+fused AdamW, encoders frozen as "
                                     "run_clm_llms.py:390-393, alignment-attention dropout on"),
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": S,
-                       "parallelism": f"dp{world}", "setup_steps": 1,
+                       "parallelism": f"dp{world}" + (" + ZeRO-1 optimizer shards (reduce-scatter / "
+                                                      "all-gather behind backward)" if runtime.shard else ""),
+                       "setup_steps": 1,
                        "loss": round(float(loss.detach()), 4)},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (csrc/gemm.hip)",
                          "achieved": round(achieved / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
@@ -277,7 +287,7 @@ def main():
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -43,6 +43,29 @@ class FusedAdamW:
         ops.adamw_(p.data, master, m, v, g, self.lr, b1, b2, self.eps, self.weight_decay,
                    self.step_count, grad_scale)
 
+    # ---- ZeRO-1 style shard (train.OverlappedStep, world > 1) ---------------------------------
+    def _shard_state(self, key, w):
+        st = self.state.get(key)
+        if st is None:
+            master = ops.cast(w.contiguous(), torch.float32) if w.dtype != torch.float32 else w.clone()
+            m = torch.empty_like(master)
+            v = torch.empty_like(master)
+            ops.fill_(m, 0.0)
+            ops.fill_(v, 0.0)
+            st = self.state[key] = (master, m, v)
+        return st
+
+    @torch.no_grad()
+    def step_shard(self, key, w, grad_shard, grad_scale: float = 1.0):
+        """update the flat parameter slice `w` (a view into one or several adjacent parameters)
+        from `grad_shard`, the rank-averaged gradient of exactly those elements.  Optimizer
+        state (fp32 master / m / v, 12 B per owned element) exists only for the slice and is
+        keyed by `key` (stable across steps: the slice a rank owns never changes)."""
+        b1, b2 = self.betas
+        master, m, v = self._shard_state(key, w)
+        ops.adamw_(w, master, m, v, grad_shard, self.lr, b1, b2, self.eps, self.weight_decay,
+                   self.step_count, grad_scale)
+
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
         self.step_count += 1

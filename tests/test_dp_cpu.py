@@ -117,3 +117,95 @@ def test_overlapped_step_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _worker_sharded(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from macaw_llm_amd.train import OverlappedStep
+
+        class ShardSGD:  # FusedAdamW's interface (step_param / step_shard) with plain SGD arithmetic
+            step_count = 0
+            shard_calls = 0
+            full_calls = 0
+
+            def step_param(self, p):
+                ShardSGD.full_calls += 1
+                p.data -= 0.5 * p.grad
+
+            def step_shard(self, key, w, g):
+                ShardSGD.shard_calls += 1
+                kp, lo, n = key
+                assert g.numel() == n == w.numel() and lo == rank * n
+                w -= 0.5 * g
+
+        torch.manual_seed(0)
+        big = torch.nn.Parameter(torch.randn(40, 32))       # 1280 = 16 * 80: sharded
+        odd = torch.nn.Parameter(torch.randn(41, 31))       # 1271: not divisible -> all-reduce path
+        small = torch.nn.Parameter(torch.randn(5))          # coalesced
+        # two parameters that are row slices of ONE buffer whose gradients are row slices of one
+        # buffer too (the fused q|k|v layout): must go out as a single reduce-scatter
+        fused = torch.randn(48, 16)
+        fa, fb = torch.nn.Parameter(torch.empty(0)), torch.nn.Parameter(torch.empty(0))
+        fa.data, fb.data = fused[:16], fused[16:]
+
+        class FusedFn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, a, b, s):
+                ctx.s = s
+                return (a.sum() + 2 * b.sum()) * s
+
+            @staticmethod
+            def backward(ctx, dy):
+                gfull = torch.empty(48, 16)
+                gfull[:16] = ctx.s
+                gfull[16:] = 2 * ctx.s
+                gfull *= (torch.arange(768.).view(48, 16) / 768 + 1) * dy
+                return gfull[:16], gfull[16:], None      # row-slice VIEWS of one buffer
+
+        w0, o0, s0, f0 = big.detach().clone(), odd.detach().clone(), small.detach().clone(), fused.clone()
+        rt = OverlappedStep([big, odd, small, fa, fb], ShardSGD(), small_threshold=100)
+        assert rt.shard
+        ok = True
+        scale = torch.arange(1280.).view(40, 32) / 1280      # element-dependent gradient: slices must line up
+        fscale = torch.cat([torch.ones(16, 16), 2 * torch.ones(32, 16)]) * (torch.arange(768.).view(48, 16) / 768 + 1)
+        for it in range(2):
+            rt.begin()
+            (FusedFn.apply(fa, fb, float(rank + 1)) + (big * scale * (rank + 1)).sum() + (odd * (rank + 3)).sum()
+             + (small * (2 * rank + 1)).sum()).backward()
+            rt.finish()
+            w0 = w0 - 0.5 * 1.5 * scale
+            o0 = o0 - 0.5 * 3.5
+            s0 = s0 - 0.5 * 2.0
+            f0 = f0 - 0.5 * 1.5 * fscale
+            ok = ok and torch.allclose(big.data, w0) and torch.allclose(odd.data, o0) and torch.allclose(small.data, s0)
+            ok = ok and torch.allclose(fused, f0) and fa.data.data_ptr() == fused.data_ptr()
+        # per step: big -> 1 shard call, fa+fb -> ONE shard call (merged run); odd + small replicated
+        ok = ok and ShardSGD.shard_calls == 4 and ShardSGD.full_calls == 4
+        if not ok:
+            print("DEBUG", rank, ShardSGD.shard_calls, ShardSGD.full_calls, (big.data - w0).abs().max().item(),
+                  (odd.data - o0).abs().max().item(), (fused - f0).abs().max().item(), flush=True)
+        # replicas identical afterwards (the all-gather really distributed the other rank's slice)
+        other = [torch.empty_like(big.data) for _ in range(world)]
+        dist.all_gather(other, big.data.clone())
+        ok = ok and torch.equal(other[0], other[1])
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_step_sharded_optimizer_gloo_world2():
+    """ZeRO-1 form: reduce-scatter -> owner updates its slice -> in-place all-gather; result equals
+    the replicated update, non-divisible and tiny tensors fall back to all-reduce"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
