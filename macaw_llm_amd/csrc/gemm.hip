@@ -1487,13 +1487,16 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
     g.counters = nullptr;
     static const int ablate = [] { const char* e = getenv("MK_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     g.ablate = ablate;
+    static const int n_cus = [] {
+      int dev = 0, cus = 256;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      return cus;
+    }();
+    // resident workgroups per CU of the chosen kernel (a function-local static here used to
+    // freeze the factor of whichever configuration happened to launch first)
+    const int slots = n_cus * (t256 ? 1 : (cfg == 7 ? 4 : 2));
     if ((cfg == 5 || cfg == 7 || cfg == 8 || (t256 && nbatch == 1)) && d->ws && !getenv("MK_GEMM_NO_STREAMK")) {
-      static const int slots = [] {
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus;
-      }() * (t256 ? 1 : (cfg == 7 ? 4 : 2));  // resident workgroups per CU
       const int T = g.tiles_m * g.tiles_n * nbatch, nkt = (d->K + bkv - 1) / bkv;
       const int R = T % slots;
       int sp = R > 0 ? slots / R : 1;
