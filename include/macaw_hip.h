@@ -70,7 +70,9 @@ typedef struct mk_gemm_desc {
   int32_t dtype;      /* MK_F32 or MK_BF16: type of A,B,C,R,bias */
   void* ws;           /* optional device scratch for the stream-K tail (fp32 partial tiles +
                          arrival counters); NULL disables it. Must not be shared by GEMMs that
-                         run concurrently on different streams. */
+                         run concurrently on different streams.  Its first 4096 bytes (the
+                         counters) must be ZERO before the first use; every launch leaves
+                         them zero again (the last arriver of a tile resets its counter). */
   int64_t ws_bytes;
 } mk_gemm_desc;
 int mk_gemm(const mk_gemm_desc* d, void* stream);

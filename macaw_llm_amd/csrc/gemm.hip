@@ -785,7 +785,10 @@ MK_DEV void v2_body(const GemmArgs& g) {
     }
     __syncthreads();
     if (!*flag) return;
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      g.counters[tail_idx] = 0;   // self-cleaning: the next launch on this stream finds zeros
+    }
     __syncthreads();
     // deterministic: sum the slabs in piece order regardless of who arrived last
 #pragma unroll
@@ -1204,7 +1207,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g) {
     }
     __syncthreads();
     if (!*flag) return;
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      g.counters[tail_idx] = 0;   // self-cleaning: the next launch on this stream finds zeros
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -1512,7 +1518,6 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
         g.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(d->ws) + 4096);
         if (R * (int)sizeof(int) > 4096) { g.dp_tiles = T; g.split = 1; }
         else {
-          (void)hipMemsetAsync(g.counters, 0, R * sizeof(int), st);
           grid.x = g.dp_tiles + R * sp;
           if (nbatch > 1) { g.lin_batch = 1; grid.z = 1; }
         }

@@ -56,6 +56,8 @@ def _workspace(device):
     ws = _WS.get(key)
     if ws is None:
         ws = _WS[key] = torch.empty(WS_BYTES, dtype=torch.uint8, device=device)
+        # the first 4 KiB are the stream-K arrival counters: zero once, the kernels leave them zero
+        fill_(ws[:4096].view(torch.float32), 0.0)
     return ws
 
 
