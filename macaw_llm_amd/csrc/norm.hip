@@ -147,6 +147,58 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const T*
     yr[c] = from_f32<T>((to_f32<T>(xr[c]) - mean) * rstd * to_f32<T>(w[c]) + to_f32<T>(b[c]));
 }
 
+// Narrow rows (CLIP d = 1024, Whisper d = 512): one WAVE per row, the row lives in registers
+// (CH x 16-byte loads per lane, read once), mean / variance by wave shuffles -- no LDS, no
+// barriers, 4 rows per workgroup.  Same two-pass fp32 arithmetic as the block form.
+template <int CH>
+__global__ __launch_bounds__(256) void layernorm_fwd_wave_kernel(const bf16* x, const bf16* w,
+                                                                 const bf16* b, bf16* y,
+                                                                 float* mean_out, float* rstd_out,
+                                                                 int rows, int cols, float eps) {
+  const int l = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16* xr = x + row * cols;
+  float v[CH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = (k * 64 + l) * 8;
+    if (c < cols) {
+      VecIO<bf16>::load(xr + c, v[k]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[k][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = (k * 64 + l) * 8;
+    if (c < cols) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+  if (l == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = (k * 64 + l) * 8;
+    if (c < cols) {
+      float wv[8], bv[8], o[8];
+      VecIO<bf16>::load(w + c, wv);
+      VecIO<bf16>::load(b + c, bv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mean) * rstd * wv[e] + bv[e];
+      VecIO<bf16>::store(y + row * cols + c, o);
+    }
+  }
+}
+
 template <typename T, int CH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const T* w,
                                                             const float* mean, const float* rstd,
@@ -313,6 +365,18 @@ extern "C" int mk_layernorm_fwd(const void* x, const void* w, const void* b, voi
                                 void* stream) {
   if (!x || !w || !b || !y || !mean || !rstd || rows <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
   dim3 grid(rows), block(256);
+  const uintptr_t al16 = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) |
+                         reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y);
+  if (dtype == MK_BF16 && cols % 8 == 0 && cols <= 1024 && !(al16 & 15)) {
+    const dim3 gw((rows + 3) / 4);
+    if (cols <= 512)
+      MK_LAUNCH((layernorm_fwd_wave_kernel<1>), gw, block, 0, MK_ST, (const bf16*)x, (const bf16*)w,
+                (const bf16*)b, (bf16*)y, mean, rstd, rows, cols, eps);
+    else
+      MK_LAUNCH((layernorm_fwd_wave_kernel<2>), gw, block, 0, MK_ST, (const bf16*)x, (const bf16*)w,
+                (const bf16*)b, (bf16*)y, mean, rstd, rows, cols, eps);
+    return mk_check_launch();
+  }
   if (dtype == MK_BF16)
     MK_LAUNCH((layernorm_fwd_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x,
                        (const bf16*)w, (const bf16*)b, (bf16*)y, mean, rstd, cols, eps);

@@ -125,11 +125,12 @@ class LlamaLayerFn(torch.autograd.Function):
             qkv = ops.linear_fwd(y1, wqkv)                    # [M, 3D]
             q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
             ldq = 3 * D
+            ops.rope_(qkv[:, :2 * D], cos, sin, pos, 2 * H, hd)   # q and k heads in one launch
         else:
             q, k, v = ops.linear_fwd(y1, wq), ops.linear_fwd(y1, wk), ops.linear_fwd(y1, wv)
             ldq = D
-        ops.rope_(q, cos, sin, pos, H, hd)
-        ops.rope_(k, cos, sin, pos, H, hd)
+            ops.rope_(q, cos, sin, pos, H, hd)
+            ops.rope_(k, cos, sin, pos, H, hd)
         att = torch.empty((M, D), dtype=x2.dtype, device=x2.device)
         use_flash = flash_ok(x2.dtype, hd)
         if use_flash:
@@ -230,8 +231,11 @@ class LlamaLayerFn(torch.autograd.Function):
             d = lambda t: TDesc(t, ldq, S * ldq)  # noqa: E731
             attention_bwd(TDesc(datt, D, S * D), d(q), d(k), d(v), probs, None, d(dq), d(dk), d(dv),
                           B, H, S, S, hd, 1.0 / math.sqrt(hd))
-        ops.rope_(dq, cos, sin, pos, H, hd, inverse=True)
-        ops.rope_(dk, cos, sin, pos, H, hd, inverse=True)
+        if dqkv is not None:
+            ops.rope_(dqkv[:, :2 * D], cos, sin, pos, 2 * H, hd, inverse=True)
+        else:
+            ops.rope_(dq, cos, sin, pos, H, hd, inverse=True)
+            ops.rope_(dk, cos, sin, pos, H, hd, inverse=True)
         dwq = dwk = dwv = None
         if wqkv is not None:
             dy1 = ops.linear_dx(dqkv, wqkv)

@@ -69,6 +69,48 @@ def test_real_dimension_llama_layer_vs_oracle(dev):
     assert ((gx - xr.grad) * valid).abs().max().item() < 0.05 * xr.grad.abs().max().item() + 1e-3
 
 
+def test_llama_13b_dimension_layer_checkpointed_vs_oracle(dev):
+    """BASELINE cfg 5 backbone dimensions (LLaMA-13B: D = 5120, FF = 13824, 40 heads) through the
+    activation-checkpointed layer (recompute=True keeps only the layer input): forward and all
+    gradients against the fp32 CPU oracle; same bf16 tolerances as the 7B layer test."""
+    D13, FF13, H13, S13, B = 5120, 13824, 40, 96, 2
+    g = torch.Generator().manual_seed(13)
+    p = "l."
+    sd = {p + f"self_attn.{n}_proj.weight": torch.randn(D13, D13, generator=g) * 0.02 for n in "qkvo"}
+    sd[p + "mlp.gate_proj.weight"] = torch.randn(FF13, D13, generator=g) * 0.02
+    sd[p + "mlp.up_proj.weight"] = torch.randn(FF13, D13, generator=g) * 0.02
+    sd[p + "mlp.down_proj.weight"] = torch.randn(D13, FF13, generator=g) * 0.02
+    sd[p + "input_layernorm.weight"] = 1 + 0.1 * torch.randn(D13, generator=g)
+    sd[p + "post_attention_layernorm.weight"] = 1 + 0.1 * torch.randn(D13, generator=g)
+    sd = {k: _bf(v).float().requires_grad_(True) for k, v in sd.items()}
+    x = _bf(torch.randn(B, S13, D13, generator=g)).float()
+    am = torch.ones(B, S13, dtype=torch.long)
+    cos, sin = restate.rotary_tables(D13 // H13, 2048)
+    mask = restate.decoder_mask(am, B, S13, torch.float32, x.device)
+    xr = x.clone().requires_grad_(True)
+    y_ref = restate.llama_layer(sd, p, xr, mask, torch.arange(S13)[None], H13, 1e-6, cos, sin)
+    dy = _bf(torch.randn(B, S13, D13, generator=g)).float()
+    y_ref.backward(dy)
+
+    w = {k: _bf(v.detach()).to(dev).requires_grad_(True) for k, v in sd.items()}
+    xd = _bf(x).to(dev).requires_grad_(True)
+    posd = torch.arange(S13, dtype=torch.int32).repeat(B).to(dev)
+    y = eng.LlamaLayerFn.apply(
+        xd, None, posd, _bf(cos).to(dev), _bf(sin).to(dev), H13, 1e-6, w[p + "self_attn.q_proj.weight"],
+        w[p + "self_attn.k_proj.weight"], w[p + "self_attn.v_proj.weight"],
+        w[p + "self_attn.o_proj.weight"], w[p + "mlp.gate_proj.weight"], w[p + "mlp.up_proj.weight"],
+        w[p + "mlp.down_proj.weight"], w[p + "input_layernorm.weight"],
+        w[p + "post_attention_layernorm.weight"], None, None, True)
+    y.backward(_bf(dy).to(dev))
+    emax, emean = _rel(y, y_ref.detach())
+    assert emax <= 3e-2 and emean <= 1e-2, (emax, emean)
+    gmax, gmean = _rel(xd.grad, xr.grad)
+    assert gmax <= 5e-2 and gmean <= 2e-2, (gmax, gmean)
+    for k in sd:
+        wmax, wmean = _rel(w[k].grad, sd[k].grad)
+        assert wmax <= 6e-2 and wmean <= 2e-2, (k, wmax, wmean)
+
+
 def test_lm_head_and_cross_entropy_at_vocab_32007(dev):
     g = torch.Generator().manual_seed(1)
     B = 2

@@ -154,7 +154,7 @@ def test_rmsnorm(dev, dtype, rows, cols):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,cols", [(50, 64), (9, 1024), (3, 20)])
+@pytest.mark.parametrize("rows,cols", [(50, 64), (9, 1024), (3, 20), (7, 512), (6, 520), (5, 1032)])
 def test_layernorm(dev, dtype, rows, cols):
     g = torch.Generator().manual_seed(rows * cols)
     x = _rand((rows, cols), dtype, g)
