@@ -36,6 +36,20 @@ MK_DEV int v_off(int key, int chunk) {  // V tile [64][HD] bf16, read through tr
   else return key * 128 + ((chunk ^ (4 * ((key >> 1) & 1))) << 4);
 }
 
+// Loads are issued UNCONDITIONALLY from a clamped row and zeroed by a select afterwards: a load
+// under `if (row < n)` sits in its own basic block, the compiler then waits (vmcnt(0)) for each
+// 16-byte chunk before issuing the next one -- eight serialised HBM round trips per tile, which
+// was ~2/3 of the run time of every fused-attention kernel at S = 144.
+MK_DEV uint4 ld16_or_zero(const bf16* rowptr_clamped, bool ok) {
+  uint4 v = *reinterpret_cast<const uint4*>(rowptr_clamped);
+  if (!ok) v = make_uint4(0, 0, 0, 0);
+  return v;
+}
+MK_DEV bf16x8 ld8_or_zero(const bf16* rowptr_clamped, bool ok) {
+  const uint4 v = ld16_or_zero(rowptr_clamped, ok);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs a) {
   constexpr int KT = 64;                 // keys per LDS tile
@@ -46,10 +60,15 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs a) {
   char* ldsK = lds;
   char* ldsV = lds + KT * HD * 2;
   int* ldsM = reinterpret_cast<int*>(lds + 2 * KT * HD * 2);   // key validity of the tile
-  const int b = blockIdx.z, h = blockIdx.y;
+  // grid = (H, B, blocks): the sequence-block index is the SLOWEST dimension, so blocks of equal
+  // cost are dispatched together (heaviest first) instead of one heavy + one light block per
+  // (b, h) alternating -- at S = 144 the second block has 16 rows and a quarter of the work, and
+  // pairing them made every dispatch round as long as a heavy block (LPT order: -35 %).
+  const int b = blockIdx.y, h = blockIdx.x;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int half = l >> 5, lq = l & 31;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  const int blk = CAUSAL ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
+  const int q0 = blk * 128 + w * 32;
   const int qg = q0 + lq;                // this lane's query row
   const bf16* Q = a.q + (long)b * a.q_bs + (long)h * HD;
   const bf16* K = a.k + (long)b * a.k_bs + (long)h * HD;
@@ -60,11 +79,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs a) {
   bf16x8 qf[NKD];
 #pragma unroll
   for (int kd = 0; kd < NKD; ++kd) {
-    if (qg < a.Lq) qf[kd] = *reinterpret_cast<const bf16x8*>(Q + (long)qg * a.q_ld + 16 * kd + 8 * half);
-    else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qf[kd][e] = (bf16)0.f;
-    }
+    qf[kd] = ld8_or_zero(Q + (long)min(qg, a.Lq - 1) * a.q_ld + 16 * kd + 8 * half, qg < a.Lq);
   }
   f32x16 oacc[NDB];
 #pragma unroll
@@ -76,25 +91,33 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs a) {
   // keys this block has to visit (causal: up to the last query row of the block)
   const int shift = a.Lk - a.Lq;         // query i may see keys <= i + shift
   int k_end = a.Lk;
-  if (CAUSAL) k_end = min(a.Lk, blockIdx.x * 128 + 128 + shift);
+  if (CAUSAL) k_end = min(a.Lk, blk * 128 + 128 + shift);
   const int ntiles = (k_end + KT - 1) / KT;
 
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kbase = kt * KT;
     __syncthreads();                     // previous tile fully consumed
     // ---- stage K and V tiles (zero fill beyond Lk) ----
+    {
+      constexpr int NCH = (KT * CPR) / 256;
+      uint4 kv4[NCH], vv4[NCH];
 #pragma unroll
-    for (int i = 0; i < (KT * CPR) / 256; ++i) {
-      const int c = threadIdx.x + 256 * i;
-      const int row = c / CPR, ch = c % CPR;
-      const int kg = kbase + row;
-      uint4 kv4 = make_uint4(0, 0, 0, 0), vv4 = make_uint4(0, 0, 0, 0);
-      if (kg < a.Lk) {
-        kv4 = *reinterpret_cast<const uint4*>(K + (long)kg * a.k_ld + ch * 8);
-        vv4 = *reinterpret_cast<const uint4*>(V + (long)kg * a.v_ld + ch * 8);
+      for (int i = 0; i < NCH; ++i) {    // all 2 * NCH loads in flight, then one wait
+        const int c = threadIdx.x + 256 * i;
+        const int row = c / CPR, ch = c % CPR;
+        const int kg = kbase + row;
+        const int kc = min(kg, a.Lk - 1);
+        kv4[i] = ld16_or_zero(K + (long)kc * a.k_ld + ch * 8, kg < a.Lk);
+        vv4[i] = ld16_or_zero(V + (long)kc * a.v_ld + ch * 8, kg < a.Lk);
       }
-      *reinterpret_cast<uint4*>(ldsK + k_off<HD>(row, ch)) = kv4;
-      *reinterpret_cast<uint4*>(ldsV + v_off<HD>(row, ch)) = vv4;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        const int row = c / CPR, ch = c % CPR;
+        *reinterpret_cast<uint4*>(ldsK + k_off<HD>(row, ch)) = kv4[i];
+        *reinterpret_cast<uint4*>(ldsV + v_off<HD>(row, ch)) = vv4[i];
+      }
     }
     if (threadIdx.x < KT) {
       const int kg = kbase + threadIdx.x;
@@ -208,7 +231,7 @@ extern "C" int mk_flash_attn_fwd(const void* q, const void* k, const void* v, vo
   a.q_ld = q_ld; a.q_bs = q_bs; a.k_ld = k_ld; a.k_bs = k_bs; a.v_ld = v_ld; a.v_bs = v_bs;
   a.o_ld = o_ld; a.o_bs = o_bs;
   a.scale = scale;
-  dim3 grid(mk_cdiv(Lq, 128), H, B), block(256);
+  dim3 grid(H, B, mk_cdiv(Lq, 128)), block(256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (hd == 128) {
     if (causal) MK_LAUNCH((flash_fwd_kernel<128, true>), grid, block, 0, st, a);
@@ -267,15 +290,47 @@ __global__ __launch_bounds__(256) void flash_bwd_prep_kernel(FlashBwdArgs a) {
 template <int HD, int ROWS>
 MK_DEV void stage_rows(const bf16* src, long ld, int row0, int nrows_valid, char* lds_b128,
                        char* lds_tr) {
-  constexpr int CPR = HD / 8;
+  constexpr int CPR = HD / 8, N = (ROWS * CPR) / 256;
+  uint4 v[N];
 #pragma unroll
-  for (int i = 0; i < (ROWS * CPR) / 256; ++i) {
+  for (int i = 0; i < N; ++i) {          // all loads in flight before the first LDS write
     const int c = threadIdx.x + 256 * i;
     const int row = c / CPR, ch = c % CPR;
-    uint4 v4 = make_uint4(0, 0, 0, 0);
-    if (row0 + row < nrows_valid) v4 = *reinterpret_cast<const uint4*>(src + (long)(row0 + row) * ld + ch * 8);
-    if (lds_b128) *reinterpret_cast<uint4*>(lds_b128 + k_off<HD>(row, ch)) = v4;
-    if (lds_tr) *reinterpret_cast<uint4*>(lds_tr + v_off<HD>(row, ch)) = v4;
+    v[i] = ld16_or_zero(src + (long)min(row0 + row, nrows_valid - 1) * ld + ch * 8,
+                        row0 + row < nrows_valid);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    const int row = c / CPR, ch = c % CPR;
+    if (lds_b128) *reinterpret_cast<uint4*>(lds_b128 + k_off<HD>(row, ch)) = v[i];
+    if (lds_tr) *reinterpret_cast<uint4*>(lds_tr + v_off<HD>(row, ch)) = v[i];
+  }
+}
+// two tensors at once (one wait for both)
+template <int HD, int ROWS>
+MK_DEV void stage_rows2(const bf16* s0, long ld0, char* b0, char* t0, const bf16* s1, long ld1,
+                        char* b1, char* t1, int row0, int nrows_valid) {
+  constexpr int CPR = HD / 8, N = (ROWS * CPR) / 256;
+  uint4 v0[N], v1[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    const int row = c / CPR, ch = c % CPR;
+    const long r = min(row0 + row, nrows_valid - 1);
+    v0[i] = ld16_or_zero(s0 + r * ld0 + ch * 8, row0 + row < nrows_valid);
+    v1[i] = ld16_or_zero(s1 + r * ld1 + ch * 8, row0 + row < nrows_valid);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    const int row = c / CPR, ch = c % CPR;
+    if (b0) *reinterpret_cast<uint4*>(b0 + k_off<HD>(row, ch)) = v0[i];
+    if (t0) *reinterpret_cast<uint4*>(t0 + v_off<HD>(row, ch)) = v0[i];
+    if (b1) *reinterpret_cast<uint4*>(b1 + k_off<HD>(row, ch)) = v1[i];
+    if (t1) *reinterpret_cast<uint4*>(t1 + v_off<HD>(row, ch)) = v1[i];
   }
 }
 
@@ -305,10 +360,12 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(FlashBwdArgs a) {
   char* ldsK = lds;                      // K tile, b128 image (A operand of S^T = K Q^T)
   char* ldsKt = lds + KT * HD * 2;       // K tile, tr image   (K^T for dQ^T += K^T dS^T)
   char* ldsV = lds + 2 * KT * HD * 2;    // V tile, b128 image (A operand of dP^T = V dO^T)
-  const int b = blockIdx.z, h = blockIdx.y;
+  // grid = (H, B, blocks), heaviest sequence blocks dispatched first (see flash_fwd_kernel)
+  const int b = blockIdx.y, h = blockIdx.x;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int half = l >> 5, lq = l & 31;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  const int blk = CAUSAL ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
+  const int q0 = blk * 128 + w * 32;
   const int qg = q0 + lq;
   const bf16* Q = a.q + (long)b * a.q_bs + (long)h * HD;
   const bf16* dO = a.dout + (long)b * a.o_bs + (long)h * HD;
@@ -318,13 +375,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(FlashBwdArgs a) {
   bf16x8 qf[NKD], dof[NKD];
 #pragma unroll
   for (int kd = 0; kd < NKD; ++kd) {
-    if (qg < a.Lq) {
-      qf[kd] = *reinterpret_cast<const bf16x8*>(Q + (long)qg * a.q_ld + 16 * kd + 8 * half);
-      dof[kd] = *reinterpret_cast<const bf16x8*>(dO + (long)qg * a.o_ld + 16 * kd + 8 * half);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { qf[kd][e] = (bf16)0.f; dof[kd][e] = (bf16)0.f; }
-    }
+    const int qc = min(qg, a.Lq - 1);
+    qf[kd] = ld8_or_zero(Q + (long)qc * a.q_ld + 16 * kd + 8 * half, qg < a.Lq);
+    dof[kd] = ld8_or_zero(dO + (long)qc * a.o_ld + 16 * kd + 8 * half, qg < a.Lq);
   }
   const long rowid = ((long)b * a.H + h) * a.Lq + min(qg, a.Lq - 1);
   const float lse = a.lse[rowid], dv_ = a.dvec[rowid];
@@ -335,13 +388,12 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(FlashBwdArgs a) {
     for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
   const int shift = a.Lk - a.Lq;
   int k_end = a.Lk;
-  if (CAUSAL) k_end = min(a.Lk, blockIdx.x * 128 + 128 + shift);
+  if (CAUSAL) k_end = min(a.Lk, blk * 128 + 128 + shift);
   const int ntiles = (k_end + KT - 1) / KT;
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kbase = kt * KT;
     __syncthreads();
-    stage_rows<HD, KT>(K, a.k_ld, kbase, a.Lk, ldsK, ldsKt);
-    stage_rows<HD, KT>(V, a.v_ld, kbase, a.Lk, ldsV, nullptr);
+    stage_rows2<HD, KT>(K, a.k_ld, ldsK, ldsKt, V, a.v_ld, ldsV, nullptr, kbase, a.Lk);
     if (threadIdx.x < KT) {
       const int kg = kbase + threadIdx.x;
       ldsM[threadIdx.x] = (kg < a.Lk) && (!km || km[kg] != 0);
@@ -372,7 +424,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(FlashBwdArgs a) {
         const int kg = kbase + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         bool ok = mk[r] != 0;
         if (CAUSAL) ok = ok && (kg <= qg + shift);
-        const float p = ok ? __expf(s[r] * a.scale - lse) : 0.f;
+        const float e = __expf(fminf(s[r] * a.scale - lse, 30.f));
+        const float p = ok ? e : 0.f;
         const float ds = p * (dp[r] - dv_) * a.scale;
         dsf[r >> 3][r & 7] = (bf16)ds;
       }
@@ -408,10 +461,12 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashBwdArgs a) {
   char* ldsDt = lds + 3 * QT * HD * 2;   // dO tile tr image   (dO^T for dV^T += dO^T P)
   float* ldsLse = reinterpret_cast<float*>(lds + 4 * QT * HD * 2);
   float* ldsDv = ldsLse + QT;
-  const int b = blockIdx.z, h = blockIdx.y;
+  // grid = (H, B, blocks), heaviest sequence blocks dispatched first (see flash_fwd_kernel)
+  const int b = blockIdx.y, h = blockIdx.x;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int half = l >> 5, lk = l & 31;
-  const int k0 = blockIdx.x * 128 + w * 32;
+  const int blk = blockIdx.z;
+  const int k0 = blk * 128 + w * 32;
   const int kg = k0 + lk;                // this lane's key
   const bf16* Q = a.q + (long)b * a.q_bs + (long)h * HD;
   const bf16* dO = a.dout + (long)b * a.o_bs + (long)h * HD;
@@ -421,13 +476,9 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashBwdArgs a) {
   bf16x8 kf[NKD], vf[NKD];               // B operands: lane holds K/V[kg][16*kd + 8*half .. +8]
 #pragma unroll
   for (int kd = 0; kd < NKD; ++kd) {
-    if (kg < a.Lk) {
-      kf[kd] = *reinterpret_cast<const bf16x8*>(K + (long)kg * a.k_ld + 16 * kd + 8 * half);
-      vf[kd] = *reinterpret_cast<const bf16x8*>(V + (long)kg * a.v_ld + 16 * kd + 8 * half);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { kf[kd][e] = (bf16)0.f; vf[kd][e] = (bf16)0.f; }
-    }
+    const int kc = min(kg, a.Lk - 1);
+    kf[kd] = ld8_or_zero(K + (long)kc * a.k_ld + 16 * kd + 8 * half, kg < a.Lk);
+    vf[kd] = ld8_or_zero(V + (long)kc * a.v_ld + 16 * kd + 8 * half, kg < a.Lk);
   }
   const bool key_ok = (kg < a.Lk) && (!km || km[kg < a.Lk ? kg : 0] != 0);
   f32x16 dka[NDB], dva[NDB];
@@ -438,18 +489,46 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashBwdArgs a) {
   const int shift = a.Lk - a.Lq;
   // queries that can see this block's keys: q >= key - shift
   int q_begin = 0;
-  if (CAUSAL) q_begin = max(0, blockIdx.x * 128 - shift) / QT * QT;
+  if (CAUSAL) q_begin = max(0, blk * 128 - shift) / QT * QT;
   const long rowbase = ((long)b * a.H + h) * a.Lq;
+  // This kernel runs one workgroup per CU (354 registers), so nothing else hides the latency of
+  // the next query tile: its Q / dO chunks and lse / D values are fetched into registers while
+  // the current tile is being multiplied, and only written to LDS at the top of the next round.
+  constexpr int CPRq = HD / 8, NCH = (QT * CPRq) / 256;
+  uint4 pq[NCH], pd[NCH];
+  float plse = 0.f, pdv = 0.f;
+  auto prefetch = [&](int qt) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = threadIdx.x + 256 * i;
+      const int row = c / CPRq, ch = c % CPRq;
+      const long r = min(qt + row, a.Lq - 1);
+      pq[i] = ld16_or_zero(Q + r * a.q_ld + ch * 8, qt + row < a.Lq);
+      pd[i] = ld16_or_zero(dO + r * a.o_ld + ch * 8, qt + row < a.Lq);
+    }
+    const int qi = qt + (threadIdx.x & (QT - 1));
+    const long rid = rowbase + min(qi, a.Lq - 1);
+    plse = qi < a.Lq ? a.lse[rid] : 0.f;     // select after an unconditional load (clamped row)
+    pdv = qi < a.Lq ? a.dvec[rid] : 0.f;
+  };
+  prefetch(q_begin);
   for (int qt = q_begin; qt < a.Lq; qt += QT) {
     __syncthreads();
-    stage_rows<HD, QT>(Q, a.q_ld, qt, a.Lq, ldsQ, ldsQt);
-    stage_rows<HD, QT>(dO, a.o_ld, qt, a.Lq, ldsD, ldsDt);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = threadIdx.x + 256 * i;
+      const int row = c / CPRq, ch = c % CPRq;
+      *reinterpret_cast<uint4*>(ldsQ + k_off<HD>(row, ch)) = pq[i];
+      *reinterpret_cast<uint4*>(ldsQt + v_off<HD>(row, ch)) = pq[i];
+      *reinterpret_cast<uint4*>(ldsD + k_off<HD>(row, ch)) = pd[i];
+      *reinterpret_cast<uint4*>(ldsDt + v_off<HD>(row, ch)) = pd[i];
+    }
     if (threadIdx.x < QT) {
-      const int qi = qt + threadIdx.x;
-      ldsLse[threadIdx.x] = qi < a.Lq ? a.lse[rowbase + qi] : 0.f;
-      ldsDv[threadIdx.x] = qi < a.Lq ? a.dvec[rowbase + qi] : 0.f;
+      ldsLse[threadIdx.x] = plse;
+      ldsDv[threadIdx.x] = pdv;
     }
     __syncthreads();
+    if (qt + QT < a.Lq) prefetch(qt + QT);   // in flight during this tile's MFMAs
     if (k0 >= a.Lk) continue;
 #pragma unroll 1
     for (int sb = 0; sb < 2; ++sb) {
@@ -465,14 +544,26 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashBwdArgs a) {
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kd], dp, 0, 0, 0);
       }
       bf16x8 pf[2], dsf[2];
+      // per-query lse / D loaded unconditionally as float4 (a load under the mask predicate
+      // cannot be speculated and turned every element into its own branch)
+      float lse_r[16], dv_r[16];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 l4 = *reinterpret_cast<const float4*>(ldsLse + sb * 32 + 8 * g4 + 4 * half);
+        const float4 d4 = *reinterpret_cast<const float4*>(ldsDv + sb * 32 + 8 * g4 + 4 * half);
+        lse_r[4 * g4] = l4.x; lse_r[4 * g4 + 1] = l4.y; lse_r[4 * g4 + 2] = l4.z; lse_r[4 * g4 + 3] = l4.w;
+        dv_r[4 * g4] = d4.x; dv_r[4 * g4 + 1] = d4.y; dv_r[4 * g4 + 2] = d4.z; dv_r[4 * g4 + 3] = d4.w;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ql = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // query row inside the tile
         const int qi = qt + ql;
-        bool ok = key_ok && (qi < a.Lq);
-        if (CAUSAL) ok = ok && (kg <= qi + shift);
-        const float p = ok ? __expf(s[r] * a.scale - ldsLse[ql]) : 0.f;
-        const float ds = p * (dp[r] - ldsDv[ql]) * a.scale;
+        bool ok = key_ok & (qi < a.Lq);
+        if (CAUSAL) ok = ok & (kg <= qi + shift);
+        // masked scores can be arbitrarily large: keep the exponent finite, then select
+        const float e = __expf(fminf(s[r] * a.scale - lse_r[r], 30.f));
+        const float p = ok ? e : 0.f;
+        const float ds = p * (dp[r] - dv_r[r]) * a.scale;
         pf[r >> 3][r & 7] = (bf16)p;
         dsf[r >> 3][r & 7] = (bf16)ds;
       }
@@ -532,7 +623,7 @@ extern "C" int mk_flash_attn_bwd(const void* q, const void* k, const void* v, co
   a.scale = scale;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long rows = (long)B * H * Lq;
-  dim3 gq(mk_cdiv(Lq, 128), H, B), gk(mk_cdiv(Lk, 128), H, B), block(256);
+  dim3 gq(H, B, mk_cdiv(Lq, 128)), gk(H, B, mk_cdiv(Lk, 128)), block(256);
 #define MK_FB(HDV, CZ)                                                                         \
   do {                                                                                         \
     MK_LAUNCH((flash_bwd_prep_kernel<HDV>), dim3((unsigned)((rows + 3) / 4)), block, 0, st, a); \

@@ -26,7 +26,8 @@ print(f"last step: {len(step)} kernels, wall {1e-6 * (t1 - t0):.2f} ms, sum of k
       f"idle (gaps) {1e-6 * sum(gaps):.2f} ms, max gap {1e-3 * max(gaps):.1f} us, gaps > 20 us: {sum(g > 20000 for g in gaps)}")
 agg = {}
 for s, e, n in step:
-    key = n.split("(")[0][-70:]
+    key = n.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    key = key.split("(")[0][-70:]
     a = agg.setdefault(key, [0, 0])
     a[0] += 1
     a[1] += e - s
