@@ -269,7 +269,7 @@ def main():
                                                       "all-gather behind backward)" if runtime.shard else ""),
                        "setup_steps": 1,
                        "loss": round(float(loss.detach()), 4)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (csrc/gemm.hip)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_v2_kernel: all mk_gemm launches of the step (csrc/gemm.hip)",
                          "achieved": round(achieved / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK, 4), "traffic": None,
                          "launches_per_step": gemm_n, "gemm_ms_per_step": round(gemm_ms, 3),
