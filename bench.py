@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=PER_GPU_BATCH)
     ap.add_argument("--model", default="real_7b")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE cfg 5 precision: q|k|v and alignment K/V "
+                    "forward GEMMs on the fp8 (e4m3) MFMA path; NOT the headline bf16 configuration")
     ap.add_argument("--layers", type=int, default=None, help="debug only: truncates the LLaMA stack "
                     "(the printed line is then marked invalid)")
     args = ap.parse_args()
@@ -206,6 +208,8 @@ def main():
     if args.layers is not None:
         cfg["llama"]["num_hidden_layers"] = args.layers
     model = build_model(cfg, dtype=torch.bfloat16, device=dev, seed=1234).train()
+    if args.fp8:
+        model.set_fp8(qkv=True, align=True)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = FusedAdamW(params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
     runtime = OverlappedStep(params, opt, overlap=not os.environ.get("MACAW_NO_OVERLAP"),
@@ -260,7 +264,9 @@ def main():
             "metric": "multimodal samples/sec (img+audio+128 tok) fwd+bwd",
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if not args.fp8 else "bf16 + fp8(e4m3) forward of q|k|v and alignment K/V GEMMs",
+            "data": "synthetic",
             "config": {"workload": ("BASELINE cfg 3: CLIP-ViT-L/14 + Whisper-base + LLaMA-7B, image + 30 s "
                                     "audio + 128-token text (S=144), fwd+bwd+fused AdamW, encoders frozen as "
                                     "run_clm_llms.py:390-393, alignment-attention dropout on"),

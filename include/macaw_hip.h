@@ -31,9 +31,10 @@ extern "C" {
 #define MK_F32 0
 #define MK_BF16 1
 #define MK_F16 2
+#define MK_FP8 3 /* OCP e4m3fn bytes: mk_gemm operands / mk_fp8_quantize output only */
 
 /* library identification: returns MK_ABI_VERSION */
-#define MK_ABI_VERSION 1
+#define MK_ABI_VERSION 2
 int mk_abi_version(void);
 
 /* ------------------------------------------------------------------ GEMM --
@@ -67,13 +68,17 @@ typedef struct mk_gemm_desc {
   int32_t bias_mode;  /* 0 none, 1 per output column (n), 2 per output row (m) */
   int32_t act;        /* 0 none, 1 gelu(erf), 2 quick_gelu (x*sigmoid(1.702x)) */
   int32_t accumulate; /* 1: C += result */
-  int32_t dtype;      /* MK_F32 or MK_BF16: type of A,B,C,R,bias */
+  int32_t dtype;      /* MK_F32 or MK_BF16: type of A,B,C,R,bias.  MK_FP8: A and B are OCP e4m3 bytes,
+                         both K-major (a_red_major = b_red_major = 0), K % 128 == 0, lda / ldb in
+                         elements (= bytes) and multiples of 16; C, R, bias are bf16 */
   void* ws;           /* optional device scratch for the stream-K tail (fp32 partial tiles +
                          arrival counters); NULL disables it. Must not be shared by GEMMs that
                          run concurrently on different streams.  Its first 4096 bytes (the
                          counters) must be ZERO before the first use; every launch leaves
                          them zero again (the last arriver of a tile resets its counter). */
   int64_t ws_bytes;
+  const float* scale_a; /* optional DEVICE scalars multiplied into alpha in the epilogue (the     */
+  const float* scale_b; /* per-tensor de-quantisation scales of fp8 operands; no host sync)       */
 } mk_gemm_desc;
 int mk_gemm(const mk_gemm_desc* d, void* stream);
 /* Optional live timing of every mk_gemm launch with HIP events on the launch stream
@@ -246,6 +251,14 @@ int mk_argmax_rows(const void* x, int64_t ld, int32_t rows, int32_t cols, int64_
 int mk_adamw(void* param, float* master, float* m, float* v, const void* grad, int64_t n,
              float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
              float grad_scale, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------ fp8 --
+ * BASELINE cfg 5 ("fp8 MFMA for alignment-attn and QKV GEMMs"): per-tensor scaled OCP e4m3.
+ * q[i] = e4m3(clamp(x[i] * 448 / amax(|x|), +-448)); *dequant_scale = amax / 448 (1 if amax == 0),
+ * written on the DEVICE and handed to mk_gemm as scale_a / scale_b: no host round trip.
+ * amax_ws: device float[1] scratch.  n % 8 == 0, 16-byte aligned x, 8-byte aligned q. */
+int mk_fp8_quantize(const void* x, int64_t n, int32_t dtype, uint8_t* q, float* amax_ws,
+                    float* dequant_scale, void* stream);
 
 /* ------------------------------------------------------ host-input pipeline --
  * The per-step CPU work of llm_trainer.py:306-381 (get_self_inputs) moved to the GPU.

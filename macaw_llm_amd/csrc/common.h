@@ -16,6 +16,7 @@
 #define MK_F32 0
 #define MK_BF16 1
 #define MK_F16 2
+#define MK_FP8 3   /* OCP e4m3fn bytes (GEMM operands only) */
 
 typedef __bf16 bf16;
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -24,6 +25,8 @@ typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 #define MK_DEV __device__ __forceinline__
 

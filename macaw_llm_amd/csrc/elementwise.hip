@@ -360,6 +360,55 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const char* src, char* dst,
     }
   }
 }
+
+// ------------------------------------------------------------------- fp8 --
+// Per-tensor scaled OCP e4m3 (v_cvt_pk_fp8_f32 on gfx950 produces e4m3fn and does NOT saturate:
+// anything above 448 becomes the NaN code 0x7f, hence the explicit clamp).
+__global__ void fp8_zero_kernel(float* amax) { amax[0] = 0.f; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_amax_kernel(const T* x, long n, float* amax) {
+  __shared__ float red[16];
+  constexpr int N = VecIO<T>::N;
+  float m = 0.f;
+  for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < n / N; c += (long)gridDim.x * 256) {
+    float v[N];
+    VecIO<T>::load(x + c * N, v);
+#pragma unroll
+    for (int k = 0; k < N; ++k) m = fmaxf(m, fabsf(v[k]));
+  }
+  m = block_max<256>(m, red);
+  // non-negative floats order like their bit patterns
+  if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(m));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_quant_kernel(const T* x, long n, uint8_t* q,
+                                                        const float* amax, float* dequant) {
+  const float am = amax[0];
+  const float sc = am > 0.f ? 448.f / am : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) dequant[0] = am > 0.f ? am / 448.f : 1.f;
+  for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < n / 8; c += (long)gridDim.x * 256) {
+    float v[8];
+    if constexpr (VecIO<T>::N == 8) {
+      VecIO<T>::load(x + c * 8, v);
+    } else {
+      float a[4], b[4];
+      VecIO<T>::load(x + c * 8, a);
+      VecIO<T>::load(x + c * 8 + 4, b);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] = a[k]; v[4 + k] = b[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = fminf(fmaxf(v[k] * sc, -448.f), 448.f);
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    *reinterpret_cast<int2*>(q + c * 8) = make_int2(lo, hi);
+  }
+}
+
 }  // namespace
 
 #define MK_ST reinterpret_cast<hipStream_t>(stream)
@@ -572,5 +621,26 @@ extern "C" int mk_swiglu2d_bwd(const void* g, const void* u, const void* da, voi
   MK_DISPATCH_T(dtype, MK_LAUNCH((swiglu2d_bwd_kernel<T>), dim3(ew_grid(rows * (cols / VecIO<T>::N))),
                                  dim3(256), 0, MK_ST, (const T*)g, (const T*)u, (const T*)da, (T*)dg,
                                  (T*)du, (long)rows, cols, (long)ld_gu, (long)ld_a));
+  return mk_check_launch();
+}
+
+extern "C" int mk_fp8_quantize(const void* x, int64_t n, int32_t dtype, uint8_t* q, float* amax_ws,
+                               float* dequant_scale, void* stream) {
+  if (!x || !q || !amax_ws || !dequant_scale || n <= 0) return MK_ERR_BAD_ARG;
+  if ((n % 8) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(q) & 7))
+    return MK_ERR_UNSUPPORTED;
+  MK_LAUNCH(fp8_zero_kernel, dim3(1), dim3(1), 0, MK_ST, amax_ws);
+  long nb = (n / 8 + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  const dim3 grid((unsigned)nb), block(256);
+  if (dtype == MK_BF16) {
+    MK_LAUNCH((fp8_amax_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x, (long)n, amax_ws);
+    MK_LAUNCH((fp8_quant_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x, (long)n, q, amax_ws,
+              dequant_scale);
+  } else if (dtype == MK_F32) {
+    MK_LAUNCH((fp8_amax_kernel<float>), grid, block, 0, MK_ST, (const float*)x, (long)n, amax_ws);
+    MK_LAUNCH((fp8_quant_kernel<float>), grid, block, 0, MK_ST, (const float*)x, (long)n, q, amax_ws,
+              dequant_scale);
+  } else return MK_ERR_UNSUPPORTED;
   return mk_check_launch();
 }

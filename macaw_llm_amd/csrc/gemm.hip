@@ -36,6 +36,7 @@ struct GemmArgs {
   int nb2;
   long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
   float alpha;
+  const float* scale_a; const float* scale_b;  // optional device scalars multiplied into alpha (fp8)
   int bias_mode, act, accumulate;
   int tiles_m, tiles_n;
   int a_vec, b_vec;  // 1: 16-byte aligned vector loads allowed
@@ -208,7 +209,9 @@ template <int FM, int FN>
 MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* C, const bf16* Rp,
                           int m0, int n0, int wm0, int wn0) {
   const int l = threadIdx.x & 63;
-  const float alpha = g.alpha;
+  float alpha = g.alpha;
+  if (g.scale_a) alpha *= g.scale_a[0];
+  if (g.scale_b) alpha *= g.scale_b[0];
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int m = m0 + wm0 + i * 32 + (l & 31);
@@ -586,7 +589,7 @@ MK_DEV void v2_frag_offsets(int wrow0, int l, int (&off)[2][4]) {
 // NWv = 4: waves 2 x 2 of 64 x 64 (2 x 2 fragments).  NWv = 8: waves 2 (M) x 4 (N) of 64 x 32
 // (2 x 1 fragments, 32 accumulator registers) -- the same tile and LDS image with twice the
 // waves per SIMD to hide LDS / barrier latency (the kernel is latency- not bandwidth-bound).
-template <bool A_RED, bool B_RED, int BKv, int NWv>
+template <bool A_RED, bool B_RED, int BKv, int NWv, bool FP8 = false>
 MK_DEV void v2_body(const GemmArgs& g) {
   constexpr int TILE_B = 128 * BKv * 2;   // bytes per operand tile
   constexpr int NP = BKv / 4 / NWv;       // LDS-DMA pieces per wave per operand tile
@@ -707,12 +710,43 @@ MK_DEV void v2_body(const GemmArgs& g) {
       acc[1][FN - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[3], F[1], acc[1][FN - 1], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                               \
   } while (0)
+// fp8 (e4m3) operands: the tile bytes, LDS image and the two 16-byte reads per fragment are
+// those of two bf16 k-steps; they feed ONE v_mfma_scale_f32_32x32x64_f8f6f4 (64 fp8 k-slots,
+// twice the bf16 MFMA rate; any k-slot permutation is fine as long as A and B agree, and both
+// are K-major here).  Scales are 2^0: the per-tensor scales are applied in the epilogue.
+#define MK_V2_CAT(LO, HI)                                                                        \
+  [&]() -> i32x8 {                                                                               \
+    const i32x4 lo_ = __builtin_bit_cast(i32x4, LO), hi_ = __builtin_bit_cast(i32x4, HI);        \
+    i32x8 r_;                                                                                    \
+    r_[0] = lo_[0]; r_[1] = lo_[1]; r_[2] = lo_[2]; r_[3] = lo_[3];                              \
+    r_[4] = hi_[0]; r_[5] = hi_[1]; r_[6] = hi_[2]; r_[7] = hi_[3];                              \
+    return r_;                                                                                   \
+  }()
+#define MK_V2_MFMA4_FP8(F, G)                                                                    \
+  do {                                                                                           \
+    const i32x8 a0_ = MK_V2_CAT(F[0], G[0]), a1_ = MK_V2_CAT(F[1], G[1]);                        \
+    const i32x8 b0_ = MK_V2_CAT(F[2], G[2]), b1_ = MK_V2_CAT(F[3], G[3]);                        \
+    __builtin_amdgcn_s_setprio(1);                                                               \
+    acc[0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b0_, a0_, acc[0][0], 0, 0, 0, 127, 0, 127); \
+    acc[0][FN - 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b1_, a0_, acc[0][FN - 1], 0, 0, 0, 127, 0, 127); \
+    acc[1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b0_, a1_, acc[1][0], 0, 0, 0, 127, 0, 127); \
+    acc[1][FN - 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b1_, a1_, acc[1][FN - 1], 0, 0, 0, 127, 0, 127); \
+    __builtin_amdgcn_s_setprio(0);                                                               \
+  } while (0)
 // fragments of k-step ks+1 are requested before the MFMAs of k-step ks (two register sets)
 #define MK_V2_COMPUTE(STAGE)                                                                     \
   do {                                                                                           \
     bf16x8 fa_[4], fb_[4];                                                                       \
     MK_V2_LOAD4(fa_, 0, STAGE);                                                                  \
     MK_V2_LOAD4(fb_, 1, STAGE);                                                                  \
+    if constexpr (FP8) {                                                                         \
+      bf16x8 fc_[4], fd_[4];                                                                     \
+      MK_V2_LOAD4(fc_, 2, STAGE);                                                                \
+      MK_V2_LOAD4(fd_, 3, STAGE);                                                                \
+      MK_V2_MFMA4_FP8(fa_, fb_);                                                                 \
+      MK_V2_MFMA4_FP8(fc_, fd_);                                                                 \
+      break;                                                                                     \
+    }                                                                                            \
     MK_V2_MFMA4(fa_);                                                                            \
     if (NKS == 4) {                                                                              \
       MK_V2_LOAD4(fa_, 2, STAGE);                                                                \
@@ -750,6 +784,8 @@ MK_DEV void v2_body(const GemmArgs& g) {
 #undef MK_V2_SYNC
 #undef MK_V2_COMPUTE
 #undef MK_V2_MFMA4
+#undef MK_V2_MFMA4_FP8
+#undef MK_V2_CAT
 #undef MK_V2_LOAD4
 #undef MK_V2_FRAG
   if (piece >= 0) {
@@ -817,6 +853,11 @@ MK_DEV void v2_body(const GemmArgs& g) {
 template <bool A_RED, bool B_RED, int BKv>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
   v2_body<A_RED, B_RED, BKv, 4>(g);
+}
+// fp8 e4m3 x fp8 e4m3 -> bf16, both operands K-major; GemmArgs dimensions are in 2-byte units
+// (K / 2, lda / 2, ldb / 2): the data path is byte-identical to the bf16 kernel.
+__global__ __launch_bounds__(256, 2) void gemm_fp8_v2_kernel(GemmArgs g) {
+  v2_body<false, false, 64, 4, true>(g);
 }
 template <bool A_RED, bool B_RED>
 __global__ __launch_bounds__(512, 4) void gemm_bf16_v4_kernel(GemmArgs g) {
@@ -1414,13 +1455,32 @@ extern "C" int mk_prof_report(const char* path) {
 
 extern "C" int mk_abi_version(void) { return MK_ABI_VERSION; }
 
-extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
+extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
+  const mk_gemm_desc* d = d_in;
   if (!d || !d->A || !d->B || !d->C) return MK_ERR_BAD_ARG;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return MK_ERR_BAD_ARG;
   if (d->nb1 < 1 || d->nb2 < 1) return MK_ERR_BAD_ARG;
   if (d->bias_mode && !d->bias) return MK_ERR_BAD_ARG;
+  // fp8 (e4m3) operands, bf16 result: both operands K-major, K a multiple of 128, 16-byte aligned
+  // rows.  The descriptor is restated in 2-byte units and takes the bf16 data path with the
+  // f8f6f4 MFMA (no other kernel handles it: anything that does not fit is an error).
+  mk_gemm_desc dd;
+  bool fp8 = false;
+  if (d->dtype == MK_FP8) {
+    if (d->a_red_major || d->b_red_major || (d->K % 128) || (d->lda % 16) || (d->ldb % 16) ||
+        (d->sA1 % 16) || (d->sA2 % 16) || (d->sB1 % 16) || (d->sB2 % 16) || !aligned16(d->A) ||
+        !aligned16(d->B))
+      return MK_ERR_UNSUPPORTED;
+    dd = *d;
+    dd.K /= 2; dd.lda /= 2; dd.ldb /= 2;
+    dd.sA1 /= 2; dd.sA2 /= 2; dd.sB1 /= 2; dd.sB2 /= 2;
+    dd.dtype = MK_BF16;
+    d = &dd;
+    fp8 = true;
+  }
   if (d->dtype != MK_F32 && d->dtype != MK_BF16) return MK_ERR_UNSUPPORTED;
   GemmArgs g;
+  g.scale_a = d->scale_a; g.scale_b = d->scale_b;
   g.A = d->A; g.B = d->B; g.C = d->C; g.R = d->R; g.bias = d->bias;
   g.M = d->M; g.N = d->N; g.K = d->K;
   g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldr = d->ldr;
@@ -1434,8 +1494,8 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
   if (g_prof_on) {
     if (!g_prof_pool.empty()) { rec.a = g_prof_pool.back().first; rec.b = g_prof_pool.back().second; g_prof_pool.pop_back(); }
     else { (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b); }
-    rec.flops = 2.0 * d->M * d->N * d->K * nbatch;
-    rec.M = d->M; rec.N = d->N; rec.K = d->K; rec.nb = nbatch;
+    rec.flops = 2.0 * d->M * d->N * d->K * nbatch * (fp8 ? 2 : 1);
+    rec.M = d->M; rec.N = d->N; rec.K = d->K * (fp8 ? 2 : 1); rec.nb = nbatch;
     rec.layout = d->a_red_major * 2 + d->b_red_major; rec.cfg = -1;
     (void)hipEventRecord(rec.a, st);
   }
@@ -1448,6 +1508,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
       return e ? atoi(e) : -1;
     }();
     int cfg = env_cfg >= 0 ? env_cfg : MK_GEMM_DEFAULT_CFG;
+    if (fp8) cfg = 5;
     const auto fits = [&](bool red, long ld, int rows) {
       const long span = red ? (long)d->K * ld * 2 : ((long)rows * ld + d->K) * 2;
       return span < 0x7fffffffL;
@@ -1464,6 +1525,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
     }
     if ((cfg == 6 || cfg == 9 || cfg == 10) && d->K % BK) cfg = 5;   // only the v2 body handles a reduction tail
     if (cfg >= 5 && !v2_ok) cfg = 0;
+    if (fp8 && cfg != 5) return MK_ERR_UNSUPPORTED;
     // Measured (profiles/): with BOTH operands reduction-major (dW = dy^T x) the global rows are
     // whole 256-B lines whatever BK is, and BK = 32 (32 KiB LDS -> 4 workgroups per CU) is 17 %
     // faster (1090-1140 vs 930-980 TFLOP/s); K-major operands would degrade to 64-B segments.
@@ -1555,6 +1617,16 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
     }                                                                                         \
     MK_LAUNCH((gemm_bf16_v2_kernel<AR, BR, 64>), grid, dim3(256), 4 * TILE_BYTES + lds_pad, st, g); \
   } while (0)
+#define MK_V2F8()                                                                             \
+  do {                                                                                        \
+    static bool attr_done = false;                                                            \
+    if (!attr_done) {                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fp8_v2_kernel),           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);  \
+      attr_done = true;                                                                       \
+    }                                                                                         \
+    MK_LAUNCH(gemm_fp8_v2_kernel, grid, dim3(256), 4 * TILE_BYTES, st, g);                    \
+  } while (0)
 #define MK_V2S(AR, BR)                                                                        \
   MK_LAUNCH((gemm_bf16_v2_kernel<AR, BR, 32>), grid, dim3(256), 2 * TILE_BYTES, st, g)
 #define MK_V4(AR, BR)                                                                         \
@@ -1611,13 +1683,15 @@ extern "C" int mk_gemm(const mk_gemm_desc* d, void* stream) {
     else if (cfg == 3) MK_PIPE(AR, BR, 256, 2);              \
     else MK_PIPE(AR, BR, 256, 3);                            \
   } while (0)
-    if (!d->a_red_major && !d->b_red_major) MK_LAYOUT(false, false);
+    if (fp8) MK_V2F8();
+    else if (!d->a_red_major && !d->b_red_major) MK_LAYOUT(false, false);
     else if (!d->a_red_major && d->b_red_major) MK_LAYOUT(false, true);
     else if (d->a_red_major && !d->b_red_major) MK_LAYOUT(true, false);
     else MK_LAYOUT(true, true);
 #undef MK_LAYOUT
 #undef MK_V2
 #undef MK_V2S
+#undef MK_V2F8
 #undef MK_V4
 #undef MK_V3
 #undef MK_V5

@@ -85,6 +85,24 @@ def attention_bwd(do: TDesc, q: TDesc, k: TDesc, v: TDesc, probs, pd, dq: TDesc,
                  sA=sP, sB=(q.bs, hd), sC=(dk.bs, hd), b_off=q.off, c_off=dk.off)
 
 
+# BASELINE cfg 5: "fp8 MFMA for alignment-attn and QKV GEMMs".  Opt-in (MM_LLMs.set_fp8): the
+# FORWARD of the fused q|k|v projection and of the alignment K/V projection of the token table
+# runs on the f8f6f4 MFMA with per-tensor e4m3 scales (activations and weights quantised on the
+# device each step); the backward stays bf16 on the bf16 operands (straight-through).
+FP8 = {"qkv": False, "align": False}
+
+
+def _fp8_linear(x, W, bias=None):
+    xq, sx = ops.quantize_fp8(x)
+    wq, sw = ops.quantize_fp8(W)
+    return ops.linear_fp8(xq, sx, wq, sw, bias=bias)
+
+
+def _fp8_ok(x, W) -> bool:
+    return (x.dtype == torch.bfloat16 and x.shape[1] % 128 == 0 and x.is_contiguous()
+            and W.is_contiguous())
+
+
 def flash_ok(dtype, hd) -> bool:
     """the fused attention kernels cover bf16 with head_dim 64 / 128"""
     return dtype == torch.bfloat16 and hd in (64, 128)
@@ -122,7 +140,10 @@ class LlamaLayerFn(torch.autograd.Function):
         FF = wg.shape[0]
         _, y1, rstd1 = ops.rmsnorm_fwd(x2, ln1, eps)
         if wqkv is not None:
-            qkv = ops.linear_fwd(y1, wqkv)                    # [M, 3D]
+            if FP8["qkv"] and _fp8_ok(y1, wqkv):
+                qkv = _fp8_linear(y1, wqkv)                   # e4m3 x e4m3 -> bf16 (cfg 5)
+            else:
+                qkv = ops.linear_fwd(y1, wqkv)                # [M, 3D]
             q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
             ldq = 3 * D
             ops.rope_(qkv[:, :2 * D], cos, sin, pos, 2 * H, hd)   # q and k heads in one launch
@@ -589,7 +610,12 @@ def _align_fwd(feats, E, prm, heads, kw, stride, p, seed):
     Lk = V + 2
     Lkp = _pad64(Lk)   # rows [V+1, Lkp) are zero: the add_zero_attn row + alignment padding
     kv = torch.empty((Lkp, 2 * D), dtype=feats.dtype, device=feats.device)
-    ops.gemm_raw(E, in_w, kv, V, 2 * D, D, D, D, 2 * D, bias=in_b[D:], bias_mode=1, b_off=D * D)
+    if FP8["align"] and _fp8_ok(E, in_w):
+        eq, se = ops.quantize_fp8(E)
+        wq8, sw8 = ops.quantize_fp8(in_w[D:])
+        ops.linear_fp8(eq, se, wq8, sw8, bias=in_b[D:], out=kv[:V])
+    else:
+        ops.gemm_raw(E, in_w, kv, V, 2 * D, D, D, D, 2 * D, bias=in_b[D:], bias_mode=1, b_off=D * D)
     ops.copy2d(bias_k, kv, 1, D, D, 2 * D, dst_off=V * 2 * D)
     ops.copy2d(bias_v, kv, 1, D, D, 2 * D, dst_off=V * 2 * D + D)
     ops.fill_(kv[V + 1:], 0.0)

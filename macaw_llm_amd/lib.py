@@ -18,8 +18,8 @@ import torch  # noqa: F401
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libmacaw_hip.so"
 
-MK_F32, MK_BF16, MK_F16 = 0, 1, 2
-ABI_VERSION = 1
+MK_F32, MK_BF16, MK_F16, MK_FP8 = 0, 1, 2, 3
+ABI_VERSION = 2
 
 _ERR = {-1: "MK_ERR_BAD_ARG", -2: "MK_ERR_UNSUPPORTED", -3: "MK_ERR_LAUNCH"}
 
@@ -42,6 +42,7 @@ class GemmDesc(C.Structure):
         ("bias_mode", C.c_int32), ("act", C.c_int32), ("accumulate", C.c_int32),
         ("dtype", C.c_int32),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+        ("scale_a", C.c_void_p), ("scale_b", C.c_void_p),
     ]
 
 
@@ -91,6 +92,7 @@ SIGNATURES = {
     "mk_argmax_rows": [_vp, _i64, _i32, _i32, _vp, _i32, _vp],
     "mk_adamw": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _i32,
                  _vp],
+    "mk_fp8_quantize": [_vp, _i64, _i32, _vp, _vp, _vp, _vp],
     "mk_image_transform": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp],
     "mk_log_mel": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp],
 }

@@ -571,6 +571,14 @@ class MM_LLMs(PreTrainedModel):
                                      eos_token_id=2, bos_token_id=1, pad_token_id=32006)
         return self.llm(inputs_embeds=text_embeddings, attention_mask=attention_mask, labels=labels)
 
+    @staticmethod
+    def set_fp8(qkv: bool = True, align: bool = True):
+        """BASELINE cfg 5: run the forward of the fused q|k|v projections and of the alignment
+        K/V projection of the token table on the fp8 (e4m3, per-tensor scale) MFMA path.  Needs
+        bf16 parameters and fused projections (LlamaDecoderLayer.fuse_projections); layers that
+        do not qualify keep the bf16 GEMM.  Process-wide switch."""
+        eng.FP8["qkv"], eng.FP8["align"] = bool(qkv), bool(align)
+
     def prepare_inputs_for_generation(self, inputs):
         """modeling.py:965-1048 — same outputs (inputs_embeds, attention_mask, labels)."""
         cfg = self.config

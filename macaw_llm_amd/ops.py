@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import lib as _L
-from .lib import GemmDesc, MacawHipError, MK_BF16, MK_F16, MK_F32
+from .lib import GemmDesc, MacawHipError, MK_BF16, MK_F16, MK_F32, MK_FP8
 
 _DT = {torch.float32: MK_F32, torch.bfloat16: MK_BF16, torch.float16: MK_F16}
 _null = None
@@ -92,6 +92,46 @@ def gemm_raw(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_red=False, b_red=False, R=No
         raise MacawHipError("gemm: mixed dtypes")
     _L.check(lib.mk_gemm(C.byref(d), _st()), "mk_gemm")
     return Cc
+
+
+# --------------------------------------------------------------------- fp8 --
+def quantize_fp8(x):
+    """per-tensor scaled OCP e4m3: returns (q uint8 tensor of x's shape, dequant scale f32[1] on
+    the device).  x bf16 / f32, contiguous, numel % 8 == 0."""
+    lib = _L.load()
+    xc = x if x.is_contiguous() else x.contiguous()
+    q = torch.empty(xc.shape, dtype=torch.uint8, device=x.device)
+    ws = torch.empty(2, dtype=torch.float32, device=x.device)
+    _L.check(lib.mk_fp8_quantize(_p(xc), xc.numel(), dt(xc), _p(q), _p(ws), _p(ws) + 4, _st()),
+             "mk_fp8_quantize")
+    return q, ws[1:2]
+
+
+def linear_fp8(xq, sx, wq, sw, bias=None, act=0, residual=None, out=None):
+    """out[M, N] (bf16) = act((xq . wq^T) * sx * sw + bias) + residual with fp8 operands xq [M, K],
+    wq [N, K] (uint8 e4m3 bytes) and their device de-quantisation scales sx, sw (f32[1])."""
+    lib = _L.load()
+    M, K = xq.shape
+    N = wq.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=xq.device)
+    d = GemmDesc()
+    d.A, d.B, d.C = _p(xq), _p(wq), _p(out)
+    d.R = _p(residual) if residual is not None else None
+    d.bias = _p(bias) if bias is not None else None
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = _rowmajor(xq), _rowmajor(wq), _rowmajor(out)
+    d.ldr = _rowmajor(residual) if residual is not None else 0
+    d.nb1 = d.nb2 = 1
+    d.alpha = 1.0
+    d.bias_mode = 1 if bias is not None else 0
+    d.act = act
+    d.dtype = MK_FP8
+    ws = _workspace(xq.device)
+    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+    d.scale_a, d.scale_b = _p(sx), _p(sw)
+    _L.check(lib.mk_gemm(C.byref(d), _st()), "mk_gemm(fp8)")
+    return out
 
 
 def linear_fwd(x, W, bias=None, act=0, residual=None, out=None, alpha=1.0):
