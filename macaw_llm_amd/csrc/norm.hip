@@ -79,14 +79,25 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* 
   }
   for (long row = blockIdx.x; row < rows; row += gridDim.x) {
     const float rs = rstd[row];
-    float dyv[CH][N], nv[CH][N];
+    float dyv[CH][N], nv[CH][N], rv[CH][N];
     float dot = 0.f;
+    // all three streams of the row are requested up front (the residual gradient is only needed
+    // after the block reduction: loading it there exposed one more HBM round trip per row)
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = threadIdx.x + 256 * k;
+#pragma unroll
+      for (int i = 0; i < N; ++i) rv[k][i] = 0.f;
+      if (c < nch) {
+        VecIO<T>::load(dy + row * cols + c * N, dyv[k]);
+        VecIO<T>::load(h + row * cols + c * N, nv[k]);
+        if (dres) VecIO<T>::load(dres + row * cols + c * N, rv[k]);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       const int c = threadIdx.x + 256 * k;
       if (c < nch) {
-        VecIO<T>::load(dy + row * cols + c * N, dyv[k]);
-        VecIO<T>::load(h + row * cols + c * N, nv[k]);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
           nv[k][i] *= rs;
@@ -102,13 +113,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* 
       const int c = threadIdx.x + 256 * k;
       if (c < nch) {
         float o[N];
-        if (dres) VecIO<T>::load(dres + row * cols + c * N, o);
-        else {
 #pragma unroll
-          for (int i = 0; i < N; ++i) o[i] = 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < N; ++i) o[i] += rs * (dyv[k][i] - nv[k][i] * dot);
+        for (int i = 0; i < N; ++i) o[i] = rv[k][i] + rs * (dyv[k][i] - nv[k][i] * dot);
         VecIO<T>::store(dx + row * cols + c * N, o);
       }
     }
