@@ -205,67 +205,114 @@ MK_DEV bf16x8 frag_load(const char* lds, int row_base, int ks) {
 
 // Epilogue for one wave's 64x64 accumulator block (2x2 fragments of 32x32).
 // D[i = n][j = m]: lane holds m = l&31, n = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+//
+// The accumulator layout gives a lane ONE output row and 4-column groups 8 apart: written
+// straight to C that is 16 B per row per instruction (32 different lines each), and a residual /
+// bias read in that layout sat in a conditional block per group -- sixteen serialised HBM round
+// trips per wave tile (an epilogue with bias + residual cost 15-50 % of a K <= 1024 GEMM).  So the
+// tile is transposed through LDS (free after the K loop): each wave stages 32 rows x (FN * 32)
+// fp32 in its private 8 KiB (float4 index XOR row: conflict-free both ways), reads them back
+// row-major -- 16 lanes per 64-column row -- and every load / store is a full 128-byte line per
+// row; the residual rows of a pass group are all requested before the first is used.
 template <int FM, int FN>
 MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* C, const bf16* Rp,
-                          int m0, int n0, int wm0, int wn0) {
-  const int l = threadIdx.x & 63;
+                          int m0, int n0, int wm0, int wn0, char* smem) {
+  constexpr int W4 = FN * 8;        // float4 per staged row
+  constexpr int RPI = 64 / W4;      // rows per pass
+  constexpr int NPASS = 32 / RPI;   // passes per 32-row fragment
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   float alpha = g.alpha;
   if (g.scale_a) alpha *= g.scale_a[0];
   if (g.scale_b) alpha *= g.scale_b[0];
+  __syncthreads();                  // every wave is done with the operand tiles in LDS
+  float* buf = reinterpret_cast<float*>(smem) + w * 2048;
+  const int srow = l & 31, sh = l >> 5;          // staging: this lane's accumulator row / half
+  const int c4 = l % W4, rsub = l / W4;          // read-back: float4 column and row inside a pass
+  const int ncol = n0 + wn0 + c4 * 4;            // first of this lane's 4 output columns
+  const bool cols_full = ncol + 3 < g.N;
+  // fast path: whole wave on aligned, in-range 4-column groups (always true off the N edge)
+  const bool fast = g.c_vec && __all(cols_full ? 1 : 0);
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias_mode == 1) {
+    const bf16* bp = reinterpret_cast<const bf16*>(g.bias);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = (float)bp[min(ncol + e, g.N - 1)];
+  }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
-    const int m = m0 + wm0 + i * 32 + (l & 31);
-    if (m >= g.M) continue;
-    float bias_m = 0.f;
-    if (g.bias_mode == 2) bias_m = (float)reinterpret_cast<const bf16*>(g.bias)[m];
+    // ---- stage fragment row block i
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
+    for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn0 + j * 32 + 8 * q + 4 * (l >> 5);
-        if (n >= g.N) continue;
-        float v[4];
+        const int cw = (j * 8 + 2 * q + sh) ^ (srow & (W4 - 1));
+        *reinterpret_cast<float4*>(buf + (srow * W4 + cw) * 4) =
+            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+      }
+    const int mbase = m0 + wm0 + i * 32 + rsub;
+    if (fast) {
+      // residual / accumulate rows of ALL passes requested up front (clamped row, discarded later)
+      bf16x4 rv[NPASS], cv[NPASS];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = alpha * acc[i][j][4 * q + e];
+      for (int p = 0; p < NPASS; ++p) {
+        const long mc = min(mbase + p * RPI, g.M - 1);
+        if (Rp) rv[p] = *reinterpret_cast<const bf16x4*>(Rp + mc * g.ldr + ncol);
+        if (g.accumulate) cv[p] = *reinterpret_cast<const bf16x4*>(C + mc * g.ldc + ncol);
+      }
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int row = p * RPI + rsub, m = mbase + p * RPI;
+        const float4 t = *reinterpret_cast<const float4*>(buf + (row * W4 + (c4 ^ (row & (W4 - 1)))) * 4);
+        float v[4] = {alpha * t.x, alpha * t.y, alpha * t.z, alpha * t.w};
         if (g.bias_mode == 1) {
-          const bf16* bp = reinterpret_cast<const bf16*>(g.bias) + n;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < g.N) v[e] += (float)bp[e];
+          for (int e = 0; e < 4; ++e) v[e] += bv[e];
         } else if (g.bias_mode == 2) {
+          const float bm = (float)reinterpret_cast<const bf16*>(g.bias)[min(m, g.M - 1)];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bias_m;
+          for (int e = 0; e < 4; ++e) v[e] += bm;
         }
         if (g.act) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], g.act);
         }
-        bf16* cp = C + (long)m * g.ldc + n;
-        const bool full = (n + 3 < g.N) && g.c_vec;
-        if (full) {
-          if (Rp) {
-            bf16x4 rv = *reinterpret_cast<const bf16x4*>(Rp + (long)m * g.ldr + n);
+        if (Rp) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-          }
-          if (g.accumulate) {
-            bf16x4 cv = *reinterpret_cast<const bf16x4*>(cp);
+          for (int e = 0; e < 4; ++e) v[e] += (float)rv[p][e];
+        }
+        if (g.accumulate) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)cv[e];
-          }
+          for (int e = 0; e < 4; ++e) v[e] += (float)cv[p][e];
+        }
+        if (m < g.M) {
           bf16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-          *reinterpret_cast<bf16x4*>(cp) = o;
-        } else {
+          *reinterpret_cast<bf16x4*>(C + (long)m * g.ldc + ncol) = o;
+        }
+      }
+    } else {
+      // N edge / unaligned C: same order of operations, element by element
+#pragma unroll 1
+      for (int p = 0; p < NPASS; ++p) {
+        const int row = p * RPI + rsub, m = mbase + p * RPI;
+        const float4 t = *reinterpret_cast<const float4*>(buf + (row * W4 + (c4 ^ (row & (W4 - 1)))) * 4);
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+        if (m >= g.M) continue;
+        float bm = 0.f;
+        if (g.bias_mode == 2) bm = (float)reinterpret_cast<const bf16*>(g.bias)[m];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (n + e < g.N) {
-              float x = v[e];
-              if (Rp) x += (float)Rp[(long)m * g.ldr + n + e];
-              if (g.accumulate) x += (float)cp[e];
-              cp[e] = (bf16)x;
-            }
-          }
+        for (int e = 0; e < 4; ++e) {
+          const int n = ncol + e;
+          if (n >= g.N) continue;
+          float x = alpha * tv[e];
+          if (g.bias_mode == 1) x += bv[e];
+          else if (g.bias_mode == 2) x += bm;
+          if (g.act) x = apply_act(x, g.act);
+          if (Rp) x += (float)Rp[(long)m * g.ldr + n];
+          bf16* cp = C + (long)m * g.ldc + n;
+          if (g.accumulate) x += (float)*cp;
+          *cp = (bf16)x;
         }
       }
     }
@@ -367,7 +414,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     }
   }
 
-  wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0);
+  wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0, smem);
 }
 
 // -------------------------------------------------- pipelined LDS-DMA kernel --
@@ -525,7 +572,7 @@ __global__ __launch_bounds__(BMv * 2) void gemm_bf16_pipe_kernel(GemmArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn[j], fm[i], acc[i][j], 0, 0, 0);
     }
   }
-  wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0);
+  wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0, smem);
 }
 
 // ------------------------------------------------ v2: issue-lean LDS-DMA kernel --
@@ -848,7 +895,7 @@ MK_DEV void v2_body(const GemmArgs& g) {
           }
     }
   }
-  wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0);
+  wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0, smem);
 }
 template <bool A_RED, bool B_RED, int BKv>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
@@ -1274,7 +1321,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g) {
           }
     }
   }
-  wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0);
+  wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0, smem);
 }
 
 // ------------------------------------------------------------------- f32 --
