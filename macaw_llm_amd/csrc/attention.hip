@@ -268,22 +268,30 @@ struct FlashBwdArgs {
   float scale;
 };
 
+// D[b, h, q] = sum_d dO * O.  HD / 8 lanes per row, 16-byte loads; consecutive lane groups take
+// consecutive HEADS of one token (contiguous in memory), so a wave reads whole 128-byte lines.
 template <int HD>
 __global__ __launch_bounds__(256) void flash_bwd_prep_kernel(FlashBwdArgs a) {
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, h, q) flattened
-  const long total = (long)a.B * a.H * a.Lq;
-  if (row >= total) return;
-  const int qi = (int)(row % a.Lq);
-  const long bh = row / a.Lq;
-  const int h = (int)(bh % a.H);
-  const long b = bh / a.H;
-  const bf16* O = a.o + b * a.o_bs + (long)qi * a.o_ld + (long)h * HD;
-  const bf16* dO = a.dout + b * a.o_bs + (long)qi * a.o_ld + (long)h * HD;
+  constexpr int LPR = HD / 8;                       // lanes per (token, head) row
+  const long g = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;   // (b, q, h) flattened, h fastest
+  const int c = threadIdx.x % LPR;
+  const long total = (long)a.B * a.Lq * a.H;
+  const bool ok = g < total;
+  const long gc = ok ? g : total - 1;
+  const int h = (int)(gc % a.H);
+  const long bq = gc / a.H;
+  const int qi = (int)(bq % a.Lq);
+  const long b = bq / a.Lq;
+  const long off = b * a.o_bs + (long)qi * a.o_ld + (long)h * HD + c * 8;
+  float o[8], d[8];
+  VecIO<bf16>::load(a.o + off, o);
+  VecIO<bf16>::load(a.dout + off, d);
   float s = 0.f;
-  for (int d = lane; d < HD; d += 64) s += (float)O[d] * (float)dO[d];
-  s = wave_sum(s);
-  if (lane == 0) a.dvec[row] = s;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += o[e] * d[e];
+#pragma unroll
+  for (int m = LPR / 2; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+  if (ok && c == 0) a.dvec[(b * a.H + h) * a.Lq + qi] = s;
 }
 
 // tile stored twice: [rows][HD] with the b128 swizzle (k_off) and with the tr swizzle (v_off)
@@ -626,7 +634,7 @@ extern "C" int mk_flash_attn_bwd(const void* q, const void* k, const void* v, co
   dim3 gq(H, B, mk_cdiv(Lq, 128)), gk(H, B, mk_cdiv(Lk, 128)), block(256);
 #define MK_FB(HDV, CZ)                                                                         \
   do {                                                                                         \
-    MK_LAUNCH((flash_bwd_prep_kernel<HDV>), dim3((unsigned)((rows + 3) / 4)), block, 0, st, a); \
+    MK_LAUNCH((flash_bwd_prep_kernel<HDV>), dim3((unsigned)((rows * (HDV / 8) + 255) / 256)), block, 0, st, a); \
     MK_LAUNCH((flash_bwd_dq_kernel<HDV, CZ>), gq, block, 0, st, a);                            \
     MK_LAUNCH((flash_bwd_dkv_kernel<HDV, CZ>), gk, block, 0, st, a);                           \
   } while (0)
