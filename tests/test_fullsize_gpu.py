@@ -320,3 +320,48 @@ def test_full_llama7b_size_independent_properties(dev, monkeypatch):
     # magnitude, test above) grows like sqrt(32) -> ~4-6 % (measured 5.7 % mean, 6.2 % max/max)
     assert emax <= 0.15 and emean <= 0.10, (emax, emean)
     assert abs(loss0.item() - ref.loss.item()) <= 2e-2 * max(1.0, abs(ref.loss.item()))
+
+
+def test_cfg4_sequence_2048_video_audio_text_full_model(dev):
+    """BASELINE cfg 4 at full size: 6 video frames + 30 s audio + text, total sequence 2048, the
+    32-layer 7B backbone.  No oracle can run this; checked: prefix geometry (integer, exact),
+    finite loss / logits / gradients, padded tail rows do not influence valid logits, and the
+    activation-checkpointed step reproduces the plain one bit for bit at this length."""
+    from macaw_llm_amd.factory import baseline_config, build_model, synthetic_inputs
+    cfg = baseline_config("real_7b")
+    model = build_model(cfg, dtype=torch.bfloat16, device=dev, seed=3, fuse=True).eval()
+    n_prefix = 2 * 2 + 6 + 51                      # audio + video: tags + pooled features
+    L = 2048 - n_prefix
+    inp = synthetic_inputs(cfg, 2, L, modalities=("audios", "videos"), seed=9, device=dev)
+    inp["attention_mask"][1, -300:] = 0            # right padding on the second sample
+    inp["labels"][1, -300:] = -100
+
+    def run(ckpt):
+        model.llm.model.gradient_checkpointing = ckpt
+        model.llm.train(ckpt)
+        model.zero_grad(set_to_none=True)
+        out = model(inputs=inp)
+        out.loss.backward()
+        return out.loss.detach().clone(), out.logits.detach(), model.llm.lm_head.weight.grad.clone(), \
+            model.llm.model.layers[0].self_attn.q_proj.weight.grad.clone()
+
+    loss0, logits0, g_head0, g_q0 = run(False)
+    assert logits0.shape == (2, 2048, 32007)
+    assert torch.isfinite(loss0) and torch.isfinite(logits0).all()
+    assert torch.isfinite(g_head0).all() and torch.isfinite(g_q0).all() and g_q0.abs().max() > 0
+    keep = logits0[0, :64].clone()
+    loss1, logits1, g_head1, g_q1 = run(True)
+    assert torch.equal(loss0, loss1) and torch.equal(g_head0, g_head1) and torch.equal(g_q0, g_q1)
+    # causal + key-padding: sample 0 is unaffected by what is fed in sample 1's padded tail
+    model.llm.eval()
+    model.llm.model.gradient_checkpointing = False
+    inp2 = dict(inp)
+    ids = inp["input_ids"].clone()
+    ids[1, -300:] = 5
+    inp2["input_ids"] = ids
+    with torch.no_grad():
+        out2 = model(inputs=inp2)
+    assert torch.equal(out2.logits[0, :64], keep)
+    a = logits1[1, n_prefix:n_prefix + (L - 300)]
+    b = out2.logits[1, n_prefix:n_prefix + (L - 300)]
+    assert torch.equal(a, b)                        # valid rows of sample 1 do not see its padded keys
