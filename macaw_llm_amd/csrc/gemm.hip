@@ -1324,6 +1324,67 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g) {
   wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0, smem);
 }
 
+// ------------------------------------------------ skinny M (decode step) --
+// y[M <= 32, N] = x W^T: one token per sample against every weight row, i.e. pure weight streaming
+// (13.5 GB per generated token at 7B).  The 128-row tile kernels push W through LDS for 128 output
+// rows of which <= 32 exist (measured 2.25 TB/s); here the MFMA roles are swapped -- 32 WEIGHT rows
+// are the M dimension of v_mfma_f32_32x32x16_bf16, the (clamped) token rows the N dimension -- so
+// a W fragment goes from HBM straight into the registers of the one wave that uses it (8 lanes of
+// 16 B = a full 128-byte line per row and 64-element K block), x comes from L2, and the 8 waves of
+// a workgroup split K and reduce through LDS.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs g) {
+  __shared__ float red[NW][16][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, h = l >> 5, r32 = l & 31;
+  const int n0 = blockIdx.x * 32;
+  const bf16* A = reinterpret_cast<const bf16*>(g.A);
+  const bf16* B = reinterpret_cast<const bf16*>(g.B);
+  const bf16* wp = B + (long)min(n0 + r32, g.N - 1) * g.ldb + 8 * h;
+  const bf16* xp = A + (long)min(r32, g.M - 1) * g.lda + 8 * h;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int nkb = g.K / 64;
+#pragma unroll 2
+  for (int kb = w; kb < nkb; kb += NW) {
+    const int k0 = kb * 64;
+    bf16x8 wf[4], xf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      wf[j] = *reinterpret_cast<const bf16x8*>(wp + k0 + 16 * j);
+      xf[j] = *reinterpret_cast<const bf16x8*>(xp + k0 + 16 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[j], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[w][e][l] = acc[e];
+  __syncthreads();
+  // wave w finishes accumulator slots e = 2w' and 2w'+1 (two consecutive output columns of row m)
+  const int m = r32;
+  constexpr int SPW = 16 / NW;     // slots per wave (2 for NW = 8)
+  float alpha = g.alpha;
+  bf16* C = reinterpret_cast<bf16*>(g.C);
+  const bf16* Rp = reinterpret_cast<const bf16*>(g.R);
+#pragma unroll
+  for (int t = 0; t < SPW; ++t) {
+    const int e = w * SPW + t;
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) v += red[ww][e][l];   // fixed order: deterministic
+    const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    if (m >= g.M || n >= g.N) continue;
+    v *= alpha;
+    if (g.bias_mode == 1) v += (float)reinterpret_cast<const bf16*>(g.bias)[n];
+    else if (g.bias_mode == 2) v += (float)reinterpret_cast<const bf16*>(g.bias)[m];
+    if (g.act) v = apply_act(v, g.act);
+    if (Rp) v += (float)Rp[(long)m * g.ldr + n];
+    bf16* cp = C + (long)m * g.ldc + n;
+    if (g.accumulate) v += (float)*cp;
+    *cp = (bf16)v;
+  }
+}
+
 // ------------------------------------------------------------------- f32 --
 // 64x64x16 tile, 4 waves (2x2) of 32x32, v_mfma_f32_16x16x4_f32 (exact f32).
 constexpr int FBM = 64, FBN = 64, FBK = 16, FPAD = 4;
@@ -1545,6 +1606,17 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     rec.M = d->M; rec.N = d->N; rec.K = d->K * (fp8 ? 2 : 1); rec.nb = nbatch;
     rec.layout = d->a_red_major * 2 + d->b_red_major; rec.cfg = -1;
     (void)hipEventRecord(rec.a, st);
+  }
+  // (measured on generate(): B = 1: 7.5 -> 6.1 ms/token, B = 8: 7.2 -> 6.5; at B = 32 the 32 distinct
+  // token rows re-read per workgroup cost more than the tile kernel's wasted rows: 8.6 vs 8.0)
+  static const int skinny_max = [] { const char* e = getenv("MK_GEMM_SKINNY_MAX_M"); return e ? atoi(e) : 16; }();
+  if (d->dtype == MK_BF16 && !fp8 && d->M <= 32 && d->M <= skinny_max && !d->a_red_major && !d->b_red_major && nbatch == 1 &&
+      (d->K % 64) == 0 && (d->lda % 8) == 0 && (d->ldb % 8) == 0 && aligned16(d->A) && aligned16(d->B) &&
+      !getenv("MK_GEMM_NO_SKINNY")) {
+    rec.cfg = 12;
+    MK_LAUNCH((gemm_skinny_kernel<8>), dim3(mk_cdiv(d->N, 32)), dim3(512), 0, st, g);
+    if (g_prof_on) { (void)hipEventRecord(rec.b, st); g_prof.push_back(rec); }
+    return mk_check_launch();
   }
   if (d->dtype == MK_BF16) {
     // kernel configuration: 5 = v2 issue-lean LDS-DMA 128x128 (needs aligned operands, K%64==0),

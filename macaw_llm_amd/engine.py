@@ -275,36 +275,44 @@ class LlamaLayerFn(torch.autograd.Function):
                 dwd, dln1 if need[14] else None, dln2 if need[15] else None, None, None, None)
 
 
-def llama_layer_cached(x2, B, Sn, t0, kc, vc, Tmax, pos, cos, sin, n_heads, eps, wq, wk, wv, wo, wg, wu,
+def llama_layer_cached(x2, B, Sn, t0, kvc, Tmax, pos, cos, sin, n_heads, eps, wq, wk, wv, wo, wg, wu,
                        wd, ln1, ln2, wqkv=None, wgu=None):
     """No-grad decoder layer over `Sn` NEW positions per sample (rows of x2 are (b, s)) that
-    start at position t0, with a preallocated KV cache kc/vc [B, Tmax, D] (post-RoPE keys,
-    modeling.py:183-195 semantics without the torch.cat per step).  Sn = prompt length for the
-    prefill (t0 = 0, causal), Sn = 1 for a decode step (attends to the t0 + 1 cached keys).
-    No attention mask (the reference's generate passes none, modeling.py:959 / SURVEY Q7)."""
+    start at position t0, with a preallocated KV cache kvc [B, Tmax, 2D] = [keys | values] per
+    position (post-RoPE keys, modeling.py:183-195 semantics without the torch.cat per step).
+    Sn = prompt length for the prefill (t0 = 0, causal), Sn = 1 for a decode step (attends to
+    the t0 + 1 cached keys).  No attention mask (the reference's generate passes none,
+    modeling.py:959 / SURVEY Q7).  With fused q|k|v storage a step is one GEMM, ONE RoPE launch
+    over the q and k heads and ONE strided copy of [k | v] into the cache."""
     M, D = x2.shape
     H, hd = n_heads, D // n_heads
     FF = wg.shape[0]
     _, y1, _ = ops.rmsnorm_fwd(x2, ln1, eps)
+    ldc = 2 * D
     if wqkv is not None:
         qkv = ops.linear_fwd(y1, wqkv)
-        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        q = qkv[:, :D]
+        ldq = 3 * D
+        ops.rope_(qkv[:, :2 * D], cos, sin, pos, 2 * H, hd)
+        ops.copy2d(qkv, kvc, Sn, 2 * D, ldq, ldc, batch=B, s_src=Sn * ldq, s_dst=Tmax * ldc, src_off=D,
+                   dst_off=t0 * ldc)
     else:
         q, k, v = ops.linear_fwd(y1, wq), ops.linear_fwd(y1, wk), ops.linear_fwd(y1, wv)
-    ldq = q.stride(0)
-    ops.rope_(q, cos, sin, pos, H, hd)
-    ops.rope_(k, cos, sin, pos, H, hd)
-    # append the new keys / values to the cache rows [t0, t0 + Sn) of every sample
-    ops.copy2d(k, kc, Sn, D, ldq, D, batch=B, s_src=Sn * ldq, s_dst=Tmax * D, dst_off=t0 * D)
-    ops.copy2d(v, vc, Sn, D, ldq, D, batch=B, s_src=Sn * ldq, s_dst=Tmax * D, dst_off=t0 * D)
+        ldq = D
+        ops.rope_(q, cos, sin, pos, H, hd)
+        ops.rope_(k, cos, sin, pos, H, hd)
+        # append the new keys / values to the cache rows [t0, t0 + Sn) of every sample
+        ops.copy2d(k, kvc, Sn, D, ldq, ldc, batch=B, s_src=Sn * ldq, s_dst=Tmax * ldc, dst_off=t0 * ldc)
+        ops.copy2d(v, kvc, Sn, D, ldq, ldc, batch=B, s_src=Sn * ldq, s_dst=Tmax * ldc, dst_off=t0 * ldc + D)
+    kc, vc = kvc[:, :, :D], kvc[:, :, D:]
     T = t0 + Sn
     att = torch.empty((M, D), dtype=x2.dtype, device=x2.device)
     scale = 1.0 / math.sqrt(hd)
     if flash_ok(x2.dtype, hd):
-        ops.flash_attn_fwd(q, kc, vc, att, B, H, Sn, T, hd, ldq, Sn * ldq, D, Tmax * D, D, Tmax * D, D,
-                           Sn * D, scale, causal=True)
+        ops.flash_attn_fwd(q, kc, vc, att, B, H, Sn, T, hd, ldq, Sn * ldq, ldc, Tmax * ldc, ldc, Tmax * ldc,
+                           D, Sn * D, scale, causal=True)
     else:
-        attention_fwd(TDesc(q, ldq, Sn * ldq), TDesc(kc, D, Tmax * D), TDesc(vc, D, Tmax * D),
+        attention_fwd(TDesc(q, ldq, Sn * ldq), TDesc(kvc, ldc, Tmax * ldc, 0), TDesc(kvc, ldc, Tmax * ldc, D),
                       TDesc(att, D, Sn * D), B, H, Sn, T, hd, scale, causal=True)
     h1 = ops.linear_fwd(att, wo, residual=x2)
     _, y2, _ = ops.rmsnorm_fwd(h1, ln2, eps)

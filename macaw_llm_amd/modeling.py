@@ -383,15 +383,14 @@ class LlamaForCausalLM(LlamaPreTrainedModel):
         layers = self.model.layers
         rot = layers[0].self_attn.rotary_emb
         cos, sin = rot.tables(Tmax, dtype, dev)
-        kc = [torch.empty((B, Tmax, D), dtype=dtype, device=dev) for _ in layers]
-        vc = [torch.empty((B, Tmax, D), dtype=dtype, device=dev) for _ in layers]
+        kvc = [torch.empty((B, Tmax, 2 * D), dtype=dtype, device=dev) for _ in layers]   # [keys | values]
 
         def run(x2, Sn, t0):
             pos = (torch.arange(t0, t0 + Sn, dtype=torch.int32, device=dev)).repeat(B)
             for i, lyr in enumerate(layers):
                 a, m = lyr.self_attn, lyr.mlp
                 x2 = eng.llama_layer_cached(
-                    x2, B, Sn, t0, kc[i], vc[i], Tmax, pos, cos, sin, a.num_heads,
+                    x2, B, Sn, t0, kvc[i], Tmax, pos, cos, sin, a.num_heads,
                     lyr.input_layernorm.variance_epsilon, a.q_proj.weight, a.k_proj.weight,
                     a.v_proj.weight, a.o_proj.weight, m.gate_proj.weight, m.up_proj.weight,
                     m.down_proj.weight, lyr.input_layernorm.weight,

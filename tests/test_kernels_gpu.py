@@ -472,3 +472,33 @@ def test_flash_attention_bwd(dev, hd, Lq, Lk, causal, masked):
         err = (got.float().cpu() - ref2).abs().max().item()
         lim = 2e-2 * ref2.abs().max().item() + 2e-3
         assert torch.isfinite(got).all() and err <= lim, (name, err, lim)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 22016, 4096), (32, 4096, 11008), (5, 107, 128),
+                                   (2, 32007, 4096), (31, 250, 192)])
+def test_gemm_skinny_decode_rows(dev, M, N, K):
+    """M <= 32 (one decode position per sample): the weight-streaming kernel (W rows as the MFMA M
+    dimension, split-K across the waves of a workgroup) with every epilogue option, against fp32
+    math on the same bf16 inputs; must agree with the tile kernel within bf16 rounding."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = _rand((M, K), torch.bfloat16, g)
+    W = (_rand((N, K), torch.bfloat16, g).float() * 0.05).to(torch.bfloat16)
+    b = _rand((N,), torch.bfloat16, g)
+    r = _rand((M, N), torch.bfloat16, g)
+    xd, Wd = x.to(dev), W.to(dev)
+    ref = x.float() @ W.float().t()
+    y = ops.linear_fwd(xd, Wd)
+    _close(y, ref, torch.bfloat16, scale=math.sqrt(K) * 0.05, what="skinny plain")
+    y = ops.linear_fwd(xd, Wd, bias=b.to(dev), act=2, residual=r.to(dev))
+    pre = ref + b.float()[None]
+    want = pre * torch.sigmoid(1.702 * pre) + r.float()
+    _close(y, want, torch.bfloat16, scale=math.sqrt(K) * 0.05 + 1.0, what="skinny bias+quick_gelu+residual")
+    c0 = _rand((M, N), torch.bfloat16, g)
+    cd = c0.to(dev).clone()
+    ops.gemm_raw(xd, Wd, cd, M, N, K, K, K, N, accumulate=True, alpha=0.5)
+    _close(cd, 0.5 * ref + c0.float(), torch.bfloat16, scale=math.sqrt(K) * 0.05 + 1.0, what="skinny accumulate")
+    # pitched output (the logits buffer is pitched) and agreement with the tile kernel
+    ldc = (N + 63) // 64 * 64
+    buf = torch.zeros((M, ldc), dtype=torch.bfloat16, device=dev)
+    ops.gemm_raw(xd, Wd, buf, M, N, K, K, K, ldc)
+    assert torch.equal(buf[:, :N], ops.linear_fwd(xd, Wd)) and not buf[:, N:].any()
