@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
   bf16* C = reinterpret_cast<bf16*>(g.C) + z1 * g.sC1 + z2 * g.sC2;
   const bf16* Rp = g.R ? reinterpret_cast<const bf16*>(g.R) + z1 * g.sR1 + z2 * g.sR2 : nullptr;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, w = tid >> 6;
   const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
 
   // LDS map: [A0 | B0 | A1 | B1], 16 KiB each.
@@ -1345,14 +1345,26 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs g) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   const int nkb = g.K / 64;
-#pragma unroll 2
-  for (int kb = w; kb < nkb; kb += NW) {
-    const int k0 = kb * 64;
+  int kb = w;
+  // two K blocks per trip: 8 weight + 8 token loads of 16 B in flight per lane
+  for (; kb + NW < nkb; kb += 2 * NW) {
+    bf16x8 wf[8], xf[8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        wf[4 * u + j] = *reinterpret_cast<const bf16x8*>(wp + (kb + u * NW) * 64 + 16 * j);
+        xf[4 * u + j] = *reinterpret_cast<const bf16x8*>(xp + (kb + u * NW) * 64 + 16 * j);
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[j], acc, 0, 0, 0);
+  }
+  if (kb < nkb) {
     bf16x8 wf[4], xf[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      wf[j] = *reinterpret_cast<const bf16x8*>(wp + k0 + 16 * j);
-      xf[j] = *reinterpret_cast<const bf16x8*>(xp + k0 + 16 * j);
+      wf[j] = *reinterpret_cast<const bf16x8*>(wp + kb * 64 + 16 * j);
+      xf[j] = *reinterpret_cast<const bf16x8*>(xp + kb * 64 + 16 * j);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[j], acc, 0, 0, 0);
@@ -1655,7 +1667,6 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     const bool t256 = cfg == 6 || cfg == 9 || cfg == 10;
     const int bm = (cfg == 3 || cfg == 4 || t256) ? 256 : 128;
     const int bn = t256 ? 256 : BN;
-    const int stages = (cfg == 2 || cfg == 4) ? 3 : 2;
     g.tiles_m = mk_cdiv(d->M, bm);
     g.tiles_n = mk_cdiv(d->N, bn);
     g.a_vec = aligned16(d->A) && (d->lda % 8 == 0) && (d->sA1 % 8 == 0) && (d->sA2 % 8 == 0);
