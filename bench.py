@@ -234,7 +234,19 @@ def main():
 
     # one untimed SETUP step: materialises the optimizer state (fp32 master / m / v, 84 GB at 7B)
     # and the allocator pools, like building the model.  The W warm-up steps follow.
-    step()
+    try:
+        step()
+    except Exception as e:  # N > 1 only: the ZeRO-1 collectives are the one path a 1-GPU pool cannot run
+        if not (world > 1 and runtime.shard):
+            raise
+        print(f"[bench] rank {rank}: sharded step failed ({e!r}); falling back to all-reduce + replicated "
+              "AdamW", file=sys.stderr, flush=True)
+        runtime.remove()
+        opt = FusedAdamW(params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+        runtime = OverlappedStep(params, opt, overlap=not os.environ.get("MACAW_NO_OVERLAP"),
+                                 overlap_optimizer=bool(os.environ.get("MACAW_OVERLAP_ADAMW")),
+                                 shard_optimizer=False)
+        step()
     for _ in range(args.warmup):
         l0 = step()
         if os.environ.get("MACAW_BENCH_VERBOSE") and rank == 0:
