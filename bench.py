@@ -39,6 +39,26 @@ MFMA_BF16_PEAK = 2.5e15   # dense, /opt/skills/guides/MI355X_MICROARCH.md:42
 ALG_TFLOP_PER_SAMPLE = 6.42
 
 
+def pmc_gemm_traffic():
+    """HBM-side bytes per mk_gemm launch from the committed rocprofv3 --pmc passes of this same
+    command (profiles/r01_step_traffic_pmc.csv: FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for
+    gfx950, + WRITE_SIZE, separate passes, last step).  PMC cannot be collected inside a timed run,
+    so the bench line carries the profiled figure; None if the profile is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_step_traffic_pmc.csv")
+    try:
+        gb, n = 0.0, 0
+        with open(path) as f:
+            for line in f:
+                c = line.strip().split(",")
+                if c[0].startswith("gemm_bf16_v2_kernel"):
+                    # the template argument list contains commas: the numeric columns are the last four
+                    n += int(c[-4])
+                    gb += float(c[-3]) + float(c[-2])
+        return round(gb * 1e9 / n) if n else None
+    except (OSError, ValueError, IndexError):
+        return None
+
+
 def cpu_baseline(threads: int) -> dict:
     """Reference algorithm on the host cores (oracle port), composed from real-dimension
     components exactly as BASELINE.md §2 prescribes; bounded to ~20 s."""
@@ -289,7 +309,10 @@ def main():
                        "loss": round(float(loss.detach()), 4)},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_v2_kernel: all mk_gemm launches of the step (csrc/gemm.hip)",
                          "achieved": round(achieved / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK, 4),
+                         "traffic": pmc_gemm_traffic(),
+                         "traffic_note": "HBM-side bytes per mk_gemm launch (rocprofv3 PMC, profiles/"
+                                         "r01_step_traffic_pmc.csv; includes Infinity-Cache hits)",
                          "launches_per_step": gemm_n, "gemm_ms_per_step": round(gemm_ms, 3),
                          "gemm_tflop_per_step": round(gemm_flops / 1e12, 2),
                          "whole_step_model_tflops": round(value / world * ALG_TFLOP_PER_SAMPLE, 1),
