@@ -43,6 +43,9 @@ class OverlappedStep:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        # RCCL reduces with AVG; gloo (CPU tests, and CUDA tensors staged through the host) only
+        # has SUM: the mean is then finished with a division
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         # force_collectives: issue the collectives even with one rank (exercises the RCCL call
         # path on a single-GPU box)
         self.collective = self.world > 1 or (force_collectives and dist.is_initialized())
@@ -93,7 +96,7 @@ class OverlappedStep:
                 return
         handle = None
         if self.collective:
-            op = dist.ReduceOp.AVG if g.is_cuda else dist.ReduceOp.SUM
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             handle = dist.all_reduce(g, op=op, group=self.group, async_op=self.overlap)
         if self.side is not None:
             cur = torch.cuda.current_stream(g.device)
@@ -104,9 +107,15 @@ class OverlappedStep:
                 self.side.wait_event(ev)
                 if handle is not None:
                     handle.wait()          # stream-ordered wait on the collective
+                    if not self._avg:
+                        self._div(g)
                 self.opt.step_param(p)
         else:
             self._pending.append((handle, p))
+
+    def _div(self, t):
+        """finish a SUM-reduced mean (gloo only; RCCL reduces with AVG)"""
+        t.div_(self.world)
 
     # ---- ZeRO-1 path ------------------------------------------------------------------------
     def _extends_run(self, p, g) -> bool:
@@ -131,7 +140,7 @@ class OverlappedStep:
             self._reduce_scatter(r["params"][0], g, w)
             return
         for p in r["params"]:                   # not divisible: replicated update after an all-reduce
-            op = dist.ReduceOp.AVG if p.grad.is_cuda else dist.ReduceOp.SUM
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             h = dist.all_reduce(p.grad, op=op, group=self.group, async_op=self.overlap)
             self._pending.append((h, p))
 
@@ -139,7 +148,7 @@ class OverlappedStep:
         n = g.numel() // self.world
         lo = self.rank * n
         gs = torch.empty(n, dtype=g.dtype, device=g.device)
-        op = dist.ReduceOp.AVG if g.is_cuda else dist.ReduceOp.SUM
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         h = dist.reduce_scatter_tensor(gs, g, op=op, group=self.group, async_op=self.overlap)
         if self.side is not None:
             gs.record_stream(self.side)
@@ -151,8 +160,8 @@ class OverlappedStep:
             self._shards.append((h, key_param, w, lo, n, gs))
 
     def _update_and_gather(self, key_param, w, lo, n, gs):
-        if not gs.is_cuda:
-            gs.div_(self.world)            # gloo (CPU tests) has no AVG
+        if not self._avg:
+            self._div(gs)                  # gloo has no AVG
         self.opt.step_shard((key_param, lo, n), w[lo:lo + n], gs)
         h = dist.all_gather_into_tensor(w, w[lo:lo + n], group=self.group, async_op=self.overlap)
         if h is not None:
@@ -168,7 +177,7 @@ class OverlappedStep:
         self._shards.clear()
         if self.collective and self._small:
             flat = torch.cat([p.grad.reshape(-1) for p in self._small])
-            op = dist.ReduceOp.AVG if flat.is_cuda else dist.ReduceOp.SUM
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             dist.all_reduce(flat, op=op, group=self.group)
             if op == dist.ReduceOp.SUM:
                 flat.div_(self.world)
@@ -181,8 +190,8 @@ class OverlappedStep:
             if handle is not None:
                 if self.overlap:
                     handle.wait()
-                if not p.grad.is_cuda:
-                    p.grad.div_(self.world)
+                if not self._avg:
+                    self._div(p.grad)
             self.opt.step_param(p)
         for p in self._small:
             self.opt.step_param(p)

@@ -63,3 +63,78 @@ def test_sharded_and_allreduce_steps_match_plain_step_through_rccl(dev):
                 assert torch.equal(params[n], ref_params[n]), (shard, n)
     finally:
         dist.destroy_process_group()
+
+
+def _worker_two_ranks_one_gpu(rank, world, port, q, shard):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from golden_util import load_case
+        from oracle import configs
+        from test_model_gpu import build_model, to_dev
+        from macaw_llm_amd.optim import FusedAdamW
+        from macaw_llm_amd.train import OverlappedStep
+        dev = torch.device("cuda:0")
+        fx = load_case("micro_all")
+        cfg = configs.get(fx["config_name"])
+        model = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=True).eval()
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = FusedAdamW(params, lr=1e-3, weight_decay=0.01)
+        rt = OverlappedStep(params, opt, small_threshold=4096, shard_optimizer=shard)
+        inp = to_dev(fx["inputs"], dev)
+        # every rank sees its own half of the batch (2 samples -> 1 each)
+        mine = {k: (v[rank:rank + 1] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 2 else v)
+                for k, v in inp.items()}
+        for _ in range(2):
+            rt.begin()
+            model(inputs=mine).loss.backward()
+            rt.finish()
+        torch.cuda.synchronize()
+        import hashlib
+        out = {n: hashlib.sha1(p.detach().float().cpu().numpy().tobytes()).hexdigest()
+               for n, p in model.named_parameters() if p.requires_grad and n in fx["state"]}
+        q.put((rank, rt.shard, out))       # digests, not tensors: the child may exit before the parent reads
+    except Exception as e:   # surfaced by the parent
+        q.put((rank, "error", repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard", [True, False])
+def test_two_ranks_share_one_gpu_through_gloo(dev, shard):
+    """World size 2 with REAL data exchange and the real fused AdamW: two processes on this one GPU,
+    collectives through gloo (CUDA tensors staged by the backend).  The ZeRO-1 step (each rank
+    owns half of every large tensor's optimizer state) must leave both replicas identical and equal
+    to the all-reduce + replicated-AdamW step."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_two_ranks_one_gpu, args=(r, 2, port, q, shard)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    if any(r[1] == "error" for r in res):
+        msg = "; ".join(str(r[2]) for r in res if r[1] == "error")
+        if "gloo" in msg.lower() or "not supported" in msg.lower() or "unsupported" in msg.lower():
+            pytest.skip(f"gloo cannot run this collective on CUDA tensors here: {msg[:200]}")
+        raise AssertionError(msg)
+    assert res[0][1] == shard and res[1][1] == shard
+    a, b = res[0][2], res[1][2]
+    assert a.keys() == b.keys()
+    assert len(a) > 20
+    for n in a:
+        assert a[n] == b[n], n                       # replicas identical after 2 steps (bit for bit)
+    globals().setdefault("_TWO_RANK_RESULTS", {})[shard] = a
+    other = globals()["_TWO_RANK_RESULTS"].get(not shard)
+    if other is not None:                            # sharded == replicated update, bit for bit
+        for n in a:
+            assert a[n] == other[n], n
