@@ -290,6 +290,14 @@ int mk_log_mel(const float* audio, int64_t ld, int32_t n_clips, int32_t n_sample
                const int32_t* mel_lo, const int32_t* mel_hi, int32_t n_mels, float* ws_logspec,
                int32_t* ws_max, void* out, int32_t dtype, void* stream);
 
+/* Multi-tensor AdamW: one launch for a whole list of tensors (same arithmetic per element as
+ * mk_adamw).  items: DEVICE array of n_items records {param, master, m, v, grad, n} (6 x 8 bytes,
+ * every pointer 16-byte aligned); chunk_start: DEVICE int64[n_items + 1], prefix sum of
+ * ceil(n / 32768) per item; n_chunks = chunk_start[n_items] (= grid size). */
+int mk_adamw_multi(const void* items, const int64_t* chunk_start, int32_t n_items, int64_t n_chunks,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                   float grad_scale, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -371,6 +371,72 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* param, float* master, flo
   }
 }
 
+
+// Multi-tensor form: ONE launch updates every parameter tensor of the step (311 tensors at 7B:
+// 311 launch ramps and ~130 sub-4-microsecond kernels for the norm weights otherwise).  A block
+// owns one MK_ADAMW_CHUNK-element slice of one tensor, found by binary search in the chunk
+// prefix; per-element arithmetic is exactly adamw_kernel's.
+struct AdamItem { void* param; float* master; float* m; float* v; const void* grad; long n; };
+constexpr long MK_ADAMW_CHUNK = 32768;
+
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamItem* items, const long* chunk_start,
+                                                          int n_items, float lr, float b1, float b2,
+                                                          float eps, float wd, float bc1, float bc2,
+                                                          float gscale) {
+  int lo = 0, hi = n_items;                 // last item whose first chunk <= blockIdx.x
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_start[mid] <= (long)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const AdamItem it = items[lo];
+  const long base = ((long)blockIdx.x - chunk_start[lo]) * MK_ADAMW_CHUNK;
+  const long end = min(base + MK_ADAMW_CHUNK, it.n);
+  T* param = reinterpret_cast<T*>(it.param);
+  const T* grad = reinterpret_cast<const T*>(it.grad);
+  constexpr int N = VecIO<T>::N;
+  const float ib1 = 1.f / bc1, ib2 = 1.f / bc2;
+  const long vec_end = base + (end - base) / N * N;
+  for (long i0 = base + (long)threadIdx.x * N; i0 < vec_end; i0 += 256L * N) {
+    float g[N], w[N], mi[N], vi[N];
+    VecIO<T>::load(grad + i0, g);
+#pragma unroll
+    for (int k = 0; k < N; k += 4) {
+      VecIO<float>::load(it.master + i0 + k, *reinterpret_cast<float(*)[4]>(&w[k]));
+      VecIO<float>::load(it.m + i0 + k, *reinterpret_cast<float(*)[4]>(&mi[k]));
+      VecIO<float>::load(it.v + i0 + k, *reinterpret_cast<float(*)[4]>(&vi[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float gk = g[k] * gscale;
+      mi[k] = b1 * mi[k] + (1.f - b1) * gk;
+      vi[k] = b2 * vi[k] + (1.f - b2) * gk * gk;
+      float wk = w[k];
+      wk -= lr * wd * wk;
+      wk -= lr * (mi[k] * ib1) / (sqrtf(vi[k] * ib2) + eps);
+      w[k] = wk;
+    }
+#pragma unroll
+    for (int k = 0; k < N; k += 4) {
+      VecIO<float>::store(it.master + i0 + k, *reinterpret_cast<float(*)[4]>(&w[k]));
+      VecIO<float>::store(it.m + i0 + k, *reinterpret_cast<float(*)[4]>(&mi[k]));
+      VecIO<float>::store(it.v + i0 + k, *reinterpret_cast<float(*)[4]>(&vi[k]));
+    }
+    VecIO<T>::store(param + i0, w);
+  }
+  for (long i = vec_end + threadIdx.x; i < end; i += 256) {
+    const float g = to_f32<T>(grad[i]) * gscale;
+    float w = it.master[i];
+    const float mi = b1 * it.m[i] + (1.f - b1) * g;
+    const float vi = b2 * it.v[i] + (1.f - b2) * g * g;
+    it.m[i] = mi; it.v[i] = vi;
+    w -= lr * wd * w;
+    w -= lr * (mi * ib1) / (sqrtf(vi * ib2) + eps);
+    it.master[i] = w;
+    param[i] = from_f32<T>(w);
+  }
+}
+
 }  // namespace
 
 #define MK_ST reinterpret_cast<hipStream_t>(stream)
@@ -530,6 +596,27 @@ extern "C" int mk_argmax_rows(const void* x, int64_t ld, int32_t rows, int32_t c
   else if (dtype == MK_F32)
     MK_LAUNCH((argmax_rows_kernel<float>), dim3(rows), dim3(256), 0, MK_ST, (const float*)x,
               (long)ld, cols, out);
+  else return MK_ERR_UNSUPPORTED;
+  return mk_check_launch();
+}
+
+extern "C" int mk_adamw_multi(const void* items, const int64_t* chunk_start, int32_t n_items,
+                              int64_t n_chunks, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int32_t step, float grad_scale, int32_t dtype,
+                              void* stream) {
+  if (!items || !chunk_start || n_items <= 0 || n_chunks <= 0 || step < 1) return MK_ERR_BAD_ARG;
+  static_assert(sizeof(AdamItem) == 48 && sizeof(long) == sizeof(int64_t), "item = 6 x 8 bytes");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  const dim3 grid((unsigned)n_chunks), block(256);
+  const AdamItem* it = reinterpret_cast<const AdamItem*>(items);
+  const long* cs = reinterpret_cast<const long*>(chunk_start);
+  if (dtype == MK_BF16)
+    MK_LAUNCH((adamw_multi_kernel<bf16>), grid, block, 0, MK_ST, it, cs, n_items, lr, beta1, beta2, eps,
+              weight_decay, bc1, bc2, grad_scale);
+  else if (dtype == MK_F32)
+    MK_LAUNCH((adamw_multi_kernel<float>), grid, block, 0, MK_ST, it, cs, n_items, lr, beta1, beta2, eps,
+              weight_decay, bc1, bc2, grad_scale);
   else return MK_ERR_UNSUPPORTED;
   return mk_check_launch();
 }

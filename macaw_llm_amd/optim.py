@@ -43,6 +43,71 @@ class FusedAdamW:
         ops.adamw_(p.data, master, m, v, g, self.lr, b1, b2, self.eps, self.weight_decay,
                    self.step_count, grad_scale)
 
+    # ---- multi-tensor form ------------------------------------------------------------------
+    _CHUNK = 32768           # elements per workgroup slice (MK_ADAMW_CHUNK in csrc/softmax.hip)
+
+    @torch.no_grad()
+    def step_params(self, params, grad_scale: float = 1.0):
+        """update every parameter of `params` that has a gradient with ONE mk_adamw_multi launch
+        per dtype (same arithmetic as step_param; the pointer table is rebuilt each step because
+        autograd allocates fresh gradients)."""
+        from . import lib as _L
+        groups = {}
+        keep = []
+        for p in params:
+            if p.grad is None:
+                continue
+            master, m, v = self._state(p)
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            ptrs = (p.data.data_ptr(), master.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr())
+            if not p.data.is_contiguous() or any(x & 15 for x in ptrs):
+                self.step_param(p, grad_scale)          # unaligned view: single-tensor kernel
+                continue
+            keep.append(g)
+            groups.setdefault((p.dtype, p.device), []).append(ptrs + (p.numel(),))
+        b1, b2 = self.betas
+        lib = _L.load()
+        for (dtype, dev), items in groups.items():
+            n = len(items)
+            host = self._host_table(n)
+            t = host[: 7 * n + 1]
+            flat = []
+            starts = [0]
+            for it in items:
+                flat.extend(it)
+                starts.append(starts[-1] + (it[5] + self._CHUNK - 1) // self._CHUNK)
+            t[: 6 * n] = torch.tensor(flat, dtype=torch.int64)
+            t[6 * n:] = torch.tensor(starts, dtype=torch.int64)
+            devt = self._dev_table(dev, 7 * n + 1)
+            devt[: 7 * n + 1].copy_(t, non_blocking=True)
+            self._table_event.record(torch.cuda.current_stream(dev))
+            _L.check(lib.mk_adamw_multi(devt.data_ptr(), devt.data_ptr() + 6 * n * 8, n, starts[-1], self.lr,
+                                        b1, b2, self.eps, self.weight_decay, self.step_count, grad_scale,
+                                        ops._DT[dtype], torch.cuda.current_stream(dev).cuda_stream),
+                     "mk_adamw_multi")
+        del keep
+
+    def _host_table(self, n):
+        """pinned staging buffer, two of them used alternately; the H2D copy of the one written two
+        calls ago has long completed (its event is checked anyway)"""
+        need = 7 * n + 1
+        st = getattr(self, "_tables", None)
+        if st is None or st[0].numel() < need:
+            st = self._tables = [torch.empty(max(need, 4096), dtype=torch.int64, pin_memory=True) for _ in range(2)]
+            self._table_events = [torch.cuda.Event(), torch.cuda.Event()]
+            self._table_flip = 0
+        self._table_flip ^= 1
+        self._table_event = self._table_events[self._table_flip]
+        self._table_event.synchronize()
+        return st[self._table_flip]
+
+    def _dev_table(self, dev, need):
+        tabs = self.__dict__.setdefault("_dev_tables", {})
+        t = tabs.get(dev)
+        if t is None or t.numel() < need:
+            t = tabs[dev] = torch.empty(max(need, 4096), dtype=torch.int64, device=dev)
+        return t
+
     # ---- ZeRO-1 style shard (train.OverlappedStep, world > 1) ---------------------------------
     def _shard_state(self, key, w):
         st = self.state.get(key)
@@ -69,5 +134,4 @@ class FusedAdamW:
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
         self.step_count += 1
-        for p in self.params:
-            self.step_param(p, grad_scale)
+        self.step_params(self.params, grad_scale)

@@ -25,6 +25,7 @@ same number whichever collective produced it).
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional
 
 import torch
@@ -186,15 +187,20 @@ class OverlappedStep:
                 n = p.grad.numel()
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
+        todo = []
         for handle, p in self._pending:
             if handle is not None:
                 if self.overlap:
                     handle.wait()
                 if not self._avg:
                     self._div(p.grad)
-            self.opt.step_param(p)
-        for p in self._small:
-            self.opt.step_param(p)
+            todo.append(p)
+        todo.extend(self._small)
+        if hasattr(self.opt, "step_params") and not os.environ.get("MACAW_ADAMW_SINGLE"):
+            self.opt.step_params(todo)      # one multi-tensor launch for everything replicated
+        else:
+            for p in todo:
+                self.opt.step_param(p)
         self._pending.clear()
         self._small.clear()
         if self.side is not None:

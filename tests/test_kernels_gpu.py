@@ -502,3 +502,30 @@ def test_gemm_skinny_decode_rows(dev, M, N, K):
     buf = torch.zeros((M, ldc), dtype=torch.bfloat16, device=dev)
     ops.gemm_raw(xd, Wd, buf, M, N, K, K, K, ldc)
     assert torch.equal(buf[:, :N], ops.linear_fwd(xd, Wd)) and not buf[:, N:].any()
+
+
+def test_adamw_multi_tensor_is_bit_identical_to_per_tensor(dev):
+    """one mk_adamw_multi launch over a mixed list (big / tiny / ragged sizes) == one mk_adamw launch
+    per tensor, bit for bit, over several steps"""
+    from macaw_llm_amd.optim import FusedAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(300, 1000), (4096,), (7,), (33, 129), (70000,), (64, 512)]
+    base = [_rand(s, torch.bfloat16, g) for s in shapes]
+
+    def make():
+        return [torch.nn.Parameter(b.clone().to(dev)) for b in base]
+
+    pa, pb = make(), make()
+    oa = FusedAdamW(pa, lr=1e-2, weight_decay=0.1)
+    ob = FusedAdamW(pb, lr=1e-2, weight_decay=0.1)
+    for step in range(3):
+        grads = [_rand(tuple(p.shape), torch.bfloat16, g).to(dev) for p in pa]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        oa.step()                                   # multi-tensor
+        ob.step_count += 1
+        for q in pb:
+            ob.step_param(q)                        # one launch per tensor
+        for p, q in zip(pa, pb):
+            assert torch.equal(p.data, q.data), (step, tuple(p.shape))
+            assert torch.equal(oa.state[p][1], ob.state[q][1]) and torch.equal(oa.state[p][2], ob.state[q][2])
