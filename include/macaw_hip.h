@@ -34,7 +34,7 @@ extern "C" {
 #define MK_FP8 3 /* OCP e4m3fn bytes: mk_gemm operands / mk_fp8_quantize output only */
 
 /* library identification: returns MK_ABI_VERSION */
-#define MK_ABI_VERSION 2
+#define MK_ABI_VERSION 3
 int mk_abi_version(void);
 
 /* ------------------------------------------------------------------ GEMM --
@@ -79,8 +79,19 @@ typedef struct mk_gemm_desc {
   int64_t ws_bytes;
   const float* scale_a; /* optional DEVICE scalars multiplied into alpha in the epilogue (the     */
   const float* scale_b; /* per-tensor de-quantisation scales of fp8 operands; no host sync)       */
+  int32_t flags;        /* MK_GEMM_*_KPAD_ZERO: that K-major operand's rows are readable and ZERO from
+                           column K up to the next multiple of 64 (a pitched buffer whose pad columns
+                           are kept zero, e.g. d(logits) [tokens, 32064] for V = 32007), so a K that
+                           is not a multiple of 64 can still take the MFMA tile kernels (the other
+                           operand must be reduction-major or padded the same way) */
 } mk_gemm_desc;
+#define MK_GEMM_A_KPAD_ZERO 1
+#define MK_GEMM_B_KPAD_ZERO 2
 int mk_gemm(const mk_gemm_desc* d, void* stream);
+/* Tuning / A-B hook: force the bf16 kernel configuration of the following mk_gemm calls
+ * (11 = 256x256 v7, 5 = 128x128 v2, 7 = v2 BK32, 0 = generic; -1 = automatic).  A forced
+ * configuration is still replaced where it is not legal for the problem. */
+int mk_gemm_set_cfg(int cfg);
 /* Optional live timing of every mk_gemm launch with HIP events on the launch stream
  * (bench.py roofline): begin, run, then end() synchronises and returns the sums. */
 int mk_prof_begin(void);

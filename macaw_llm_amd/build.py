@@ -19,9 +19,9 @@ CSRC = PKG / "csrc"
 OBJ = PKG / "csrc" / "_obj"
 LIB = PKG / "libmacaw_hip.so"
 ARCH = "gfx950"
-SOURCES = ["gemm.hip", "norm.hip", "elementwise.hip", "softmax.hip", "attention.hip",
+SOURCES = ["gemm.hip", "gemm_v7.hip", "norm.hip", "elementwise.hip", "softmax.hip", "attention.hip",
            "preprocess.hip"]
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", *os.environ.get("MK_EXTRA_FLAGS", "").split(),
          "-Wno-unused-result"]
 
 
@@ -43,7 +43,7 @@ def _digest(paths) -> str:
 
 def build(force: bool = False, verbose: bool = True) -> Path:
     srcs = [CSRC / s for s in SOURCES]
-    deps = srcs + [CSRC / "common.h", PKG.parent / "include" / "macaw_hip.h"]
+    deps = srcs + [CSRC / "common.h", CSRC / "gemm_common.h", PKG.parent / "include" / "macaw_hip.h"]
     stamp = OBJ / "stamp.txt"
     dig = _digest(deps)
     if not force and LIB.exists() and stamp.exists() and stamp.read_text() == dig:
@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stderr[-4000:]}")
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -22,59 +22,14 @@
 // Replaces: nn.Linear / torch.matmul call sites listed in include/macaw_hip.h.
 #include "common.h"
 #include "../../include/macaw_hip.h"
+#include "gemm_common.h"
 #include <cstdio>
 #include <cstdlib>
 #include <utility>
 #include <vector>
 
 namespace {
-
-struct GemmArgs {
-  const void* A; const void* B; void* C; const void* R; const void* bias;
-  int M, N, K;
-  long lda, ldb, ldc, ldr;
-  int nb2;
-  long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
-  float alpha;
-  const float* scale_a; const float* scale_b;  // optional device scalars multiplied into alpha (fp8)
-  int bias_mode, act, accumulate;
-  int tiles_m, tiles_n;
-  int a_vec, b_vec;  // 1: 16-byte aligned vector loads allowed
-  int c_vec;         // 1: vector C/R access allowed
-  // stream-K tail (v2 kernel only): blocks [0, dp_tiles) own whole tiles; the remaining
-  // tiles are cut into `split` K-pieces of `kt_per_piece` K-tiles, one block each.
-  int dp_tiles, split, kt_per_piece;
-  int lin_batch;   // 1: batch index is folded into the linear tile index (grid.z == 1)
-  int ablate;      // debug only (MK_GEMM_ABLATE): 1 = skip global->LDS, 2 = skip barrier wait
-  float* ws;       // fp32 slabs [tail tile][piece][64 regs][256 threads]
-  int* counters;   // arrival counter per tail tile (zeroed by the launcher)
-};
-
-MK_DEV float apply_act(float v, int act) {
-  if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-  if (act == 2) return v / (1.0f + __expf(-1.702f * v));
-  return v;
-}
-
-// XCD-aware + grouped tile order (cdna_hip_programming.md T1, bijective form).
-MK_DEV int xcd_remap(int bid, int nwg) {
-  const int xcd = bid & 7;
-  const int q = nwg >> 3, r = nwg & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
-MK_DEV void tile_from_index(int wg, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M);
-MK_DEV void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
-  tile_from_index(xcd_remap(bid, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn, 8);
-}
-MK_DEV void tile_from_index(int wg, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M = 8) {
-  const int per_group = GROUP_M * tiles_n;
-  const int group = wg / per_group;
-  const int first_m = group * GROUP_M;
-  const int gsize = min(tiles_m - first_m, GROUP_M);
-  const int in_g = wg - group * per_group;
-  tm = first_m + in_g % gsize;
-  tn = in_g / gsize;
-}
+using namespace mkg;
 
 // ------------------------------------------------------------------ bf16 --
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -203,121 +158,6 @@ MK_DEV bf16x8 frag_load(const char* lds, int row_base, int ks) {
   }
 }
 
-// Epilogue for one wave's 64x64 accumulator block (2x2 fragments of 32x32).
-// D[i = n][j = m]: lane holds m = l&31, n = (reg&3) + 8*(reg>>2) + 4*(l>>5).
-//
-// The accumulator layout gives a lane ONE output row and 4-column groups 8 apart: written
-// straight to C that is 16 B per row per instruction (32 different lines each), and a residual /
-// bias read in that layout sat in a conditional block per group -- sixteen serialised HBM round
-// trips per wave tile (an epilogue with bias + residual cost 15-50 % of a K <= 1024 GEMM).  So the
-// tile is transposed through LDS (free after the K loop): each wave stages 32 rows x (FN * 32)
-// fp32 in its private 8 KiB (float4 index XOR row: conflict-free both ways), reads them back
-// row-major -- 16 lanes per 64-column row -- and every load / store is a full 128-byte line per
-// row; the residual rows of a pass group are all requested before the first is used.
-template <int FM, int FN>
-MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* C, const bf16* Rp,
-                          int m0, int n0, int wm0, int wn0, char* smem) {
-  constexpr int W4 = FN * 8;        // float4 per staged row
-  constexpr int RPI = 64 / W4;      // rows per pass
-  constexpr int NPASS = 32 / RPI;   // passes per 32-row fragment
-  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float alpha = g.alpha;
-  if (g.scale_a) alpha *= g.scale_a[0];
-  if (g.scale_b) alpha *= g.scale_b[0];
-  __syncthreads();                  // every wave is done with the operand tiles in LDS
-  float* buf = reinterpret_cast<float*>(smem) + w * 2048;
-  const int srow = l & 31, sh = l >> 5;          // staging: this lane's accumulator row / half
-  const int c4 = l % W4, rsub = l / W4;          // read-back: float4 column and row inside a pass
-  const int ncol = n0 + wn0 + c4 * 4;            // first of this lane's 4 output columns
-  const bool cols_full = ncol + 3 < g.N;
-  // fast path: whole wave on aligned, in-range 4-column groups (always true off the N edge)
-  const bool fast = g.c_vec && __all(cols_full ? 1 : 0);
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (g.bias_mode == 1) {
-    const bf16* bp = reinterpret_cast<const bf16*>(g.bias);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) bv[e] = (float)bp[min(ncol + e, g.N - 1)];
-  }
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    // ---- stage fragment row block i
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int cw = (j * 8 + 2 * q + sh) ^ (srow & (W4 - 1));
-        *reinterpret_cast<float4*>(buf + (srow * W4 + cw) * 4) =
-            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-      }
-    const int mbase = m0 + wm0 + i * 32 + rsub;
-    if (fast) {
-      // residual / accumulate rows of ALL passes requested up front (clamped row, discarded later)
-      bf16x4 rv[NPASS], cv[NPASS];
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        const long mc = min(mbase + p * RPI, g.M - 1);
-        if (Rp) rv[p] = *reinterpret_cast<const bf16x4*>(Rp + mc * g.ldr + ncol);
-        if (g.accumulate) cv[p] = *reinterpret_cast<const bf16x4*>(C + mc * g.ldc + ncol);
-      }
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        const int row = p * RPI + rsub, m = mbase + p * RPI;
-        const float4 t = *reinterpret_cast<const float4*>(buf + (row * W4 + (c4 ^ (row & (W4 - 1)))) * 4);
-        float v[4] = {alpha * t.x, alpha * t.y, alpha * t.z, alpha * t.w};
-        if (g.bias_mode == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bv[e];
-        } else if (g.bias_mode == 2) {
-          const float bm = (float)reinterpret_cast<const bf16*>(g.bias)[min(m, g.M - 1)];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bm;
-        }
-        if (g.act) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], g.act);
-        }
-        if (Rp) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rv[p][e];
-        }
-        if (g.accumulate) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)cv[p][e];
-        }
-        if (m < g.M) {
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-          *reinterpret_cast<bf16x4*>(C + (long)m * g.ldc + ncol) = o;
-        }
-      }
-    } else {
-      // N edge / unaligned C: same order of operations, element by element
-#pragma unroll 1
-      for (int p = 0; p < NPASS; ++p) {
-        const int row = p * RPI + rsub, m = mbase + p * RPI;
-        const float4 t = *reinterpret_cast<const float4*>(buf + (row * W4 + (c4 ^ (row & (W4 - 1)))) * 4);
-        const float tv[4] = {t.x, t.y, t.z, t.w};
-        if (m >= g.M) continue;
-        float bm = 0.f;
-        if (g.bias_mode == 2) bm = (float)reinterpret_cast<const bf16*>(g.bias)[m];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = ncol + e;
-          if (n >= g.N) continue;
-          float x = alpha * tv[e];
-          if (g.bias_mode == 1) x += bv[e];
-          else if (g.bias_mode == 2) x += bm;
-          if (g.act) x = apply_act(x, g.act);
-          if (Rp) x += (float)Rp[(long)m * g.ldr + n];
-          bf16* cp = C + (long)m * g.ldc + n;
-          if (g.accumulate) x += (float)*cp;
-          *cp = (bf16)x;
-        }
-      }
-    }
-  }
-}
 
 template <bool A_RED, bool B_RED, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
@@ -414,164 +254,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     }
   }
 
-  wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0, smem);
-}
-
-// -------------------------------------------------- pipelined LDS-DMA kernel --
-// Generalisation of the kernel above: BMv x 128 x 64 block tile with BMv/64*2 waves (each wave
-// still 64x64), STAGES LDS buffers filled by global_load_lds, and a COUNTED vmcnt wait so that
-// with 3 stages the loads of tile kt+1 stay in flight across the barrier that publishes tile kt
-// (prefetch distance two K-tiles; cdna_hip_programming.md "Pipelining across barriers").
-template <int ROWS, int NT, bool RED_MAJOR>
-MK_DEV void ptile_slow(const bf16* base, long ld, int row0, int k0, int R, int K, bool vec,
-                       char* lds) {
-  constexpr int CH = ROWS * 8 / NT;
-  const int tid = threadIdx.x;
-#pragma unroll 1
-  for (int i = 0; i < CH; ++i) {
-    const int c = tid + NT * i;
-    uint4 v;
-    int off;
-    if constexpr (!RED_MAJOR) {
-      const int row = c >> 3, kc = c & 7;
-      const int gr = row0 + row, gk = k0 + kc * 8;
-      const int valid = (gr < R) ? min(max(K - gk, 0), 8) : 0;
-      v = load_chunk_slow(base + (long)gr * ld + gk, valid, vec);
-      off = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
-    } else {
-      constexpr int CPR = ROWS / 8;  // 16-B chunks per k-row
-      const int kr = c / CPR, mc = c % CPR;
-      const int gk = k0 + kr, gr = row0 + mc * 8;
-      const int valid = (gk < K) ? min(max(R - gr, 0), 8) : 0;
-      v = load_chunk_slow(base + (long)gk * ld + gr, valid, vec);
-      off = kr * (ROWS * 2) + ((mc ^ (4 * (kr & 3))) << 4);
-    }
-    *reinterpret_cast<uint4*>(lds + off) = v;
-  }
-}
-template <int ROWS, int NW, bool RED_MAJOR>
-MK_DEV void ptile_glds(const bf16* base, long ld, int row0, int k0, char* lds) {
-  constexpr int PIECES = ROWS / 8;  // 1-KiB pieces of the ROWS x 64 bf16 tile
-  constexpr int PER = PIECES / NW;
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int p = w + NW * i;
-    const bf16* gp;
-    if constexpr (!RED_MAJOR) {
-      const int row = p * 8 + (l >> 3);
-      const int kc = (l & 7) ^ ((row >> 1) & 7);
-      gp = base + (long)(row0 + row) * ld + k0 + kc * 8;
-    } else {
-      constexpr int CPR = ROWS / 8;
-      const int q = p * 64 + l;
-      const int kr = q / CPR, cc = q % CPR;
-      const int mc = cc ^ (4 * (kr & 3));
-      gp = base + (long)(k0 + kr) * ld + row0 + mc * 8;
-    }
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)gp,
-        (__attribute__((address_space(3))) void*)(lds + p * 1024), 16, 0, 0);
-  }
-}
-template <int ROWS, bool RED_MAJOR>
-MK_DEV bf16x8 pfrag_load(const char* lds, int row_base, int ks) {
-  const int l = threadIdx.x & 63;
-  if constexpr (!RED_MAJOR) {
-    const int row = row_base + (l & 31);
-    const int kc = ks * 2 + (l >> 5);
-    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
-  } else {
-    const int li = l & 15;
-    const int col = row_base + 16 * ((l >> 4) & 1) + 4 * (li & 3);
-    const int kr0 = ks * 16 + 8 * (l >> 5) + (li >> 2);
-    bf16x8 out;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int kr = kr0 + 4 * r;
-      const int off = kr * (ROWS * 2) + (((col >> 3) ^ (4 * (kr & 3))) << 4) + ((col & 7) << 1);
-      bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4*)(lds + off));
-      out[4 * r + 0] = t[0]; out[4 * r + 1] = t[1]; out[4 * r + 2] = t[2]; out[4 * r + 3] = t[3];
-    }
-    return out;
-  }
-}
-
-template <bool A_RED, bool B_RED, int BMv, int STAGES>
-__global__ __launch_bounds__(BMv * 2) void gemm_bf16_pipe_kernel(GemmArgs g) {
-  constexpr int NW = BMv / 64 * 2, NT = NW * 64;
-  constexpr int A_BYTES = BMv * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int G = (BMv / 8) / NW + 16 / NW;  // glds instructions per wave per stage
-  static_assert(G == 8 || G == 6, "vmcnt literals below");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int tm, tn;
-  tile_coords(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
-  const int z = blockIdx.z, z1 = z / g.nb2, z2 = z - z1 * g.nb2;
-  const bf16* A = reinterpret_cast<const bf16*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
-  const bf16* B = reinterpret_cast<const bf16*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
-  bf16* C = reinterpret_cast<bf16*>(g.C) + z1 * g.sC1 + z2 * g.sC2;
-  const bf16* Rp = g.R ? reinterpret_cast<const bf16*>(g.R) + z1 * g.sR1 + z2 * g.sR2 : nullptr;
-  const int m0 = tm * BMv, n0 = tn * BN;
-  const int w = threadIdx.x >> 6;
-  const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int nk = (g.K + BK - 1) / BK;
-  const bool rows_ok = g.a_vec && g.b_vec && (m0 + BMv <= g.M) && (n0 + BN <= g.N);  // block-uniform
-  auto fast = [&](int kt) { return rows_ok && ((kt + 1) * BK <= g.K); };
-  auto stage = [&](int kt) {
-    char* buf = smem + (kt % STAGES) * STAGE_BYTES;
-    const int k0 = kt * BK;
-    if (fast(kt)) {
-      ptile_glds<BMv, NW, A_RED>(A, g.lda, m0, k0, buf);
-      ptile_glds<BN, NW, B_RED>(B, g.ldb, n0, k0, buf + A_BYTES);
-    } else {
-      ptile_slow<BMv, NT, A_RED>(A, g.lda, m0, k0, g.M, g.K, g.a_vec, buf);
-      ptile_slow<BN, NT, B_RED>(B, g.ldb, n0, k0, g.N, g.K, g.b_vec, buf + A_BYTES);
-    }
-  };
-#pragma unroll
-  for (int s0 = 0; s0 < STAGES - 1; ++s0)
-    if (s0 < nk) stage(s0);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt must have landed; at most the (fast) tile kt+1 may stay in flight
-    bool keep = false;
-    if constexpr (STAGES == 3) keep = (kt + 1 < nk) && fast(kt + 1);
-    if (keep) {
-      if constexpr (G == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1);
-    const char* la = smem + (kt % STAGES) * STAGE_BYTES;
-    const char* lb = la + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 fm[2], fn[2];
-      fm[0] = pfrag_load<BMv, A_RED>(la, wm0, ks);
-      fm[1] = pfrag_load<BMv, A_RED>(la, wm0 + 32, ks);
-      fn[0] = pfrag_load<BN, B_RED>(lb, wn0, ks);
-      fn[1] = pfrag_load<BN, B_RED>(lb, wn0 + 32, ks);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn[j], fm[i], acc[i][j], 0, 0, 0);
-    }
-  }
   wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0, smem);
 }
 
@@ -680,14 +362,17 @@ MK_DEV void v2_body(const GemmArgs& g) {
   const int wm0 = NWv == 8 ? (w >> 2) * 64 : (w >> 1) * 64;
   const int wn0 = NWv == 8 ? (w & 3) * 32 : (w & 1) * 64;
 
+  // (the hardware range check is per DWORD: with an odd number of valid rows the last element of
+  // the last k-row shares its dword with the first out-of-range one and would load as zero, so
+  // the bound is rounded up to the dword; that element lies inside the pitch since ld % 8 == 0)
   // buffer descriptors (tile-relative bases keep voffset small; num_records bounds the
   // reduction-major over-read of the last K row)
   const bf16* abase = A_RED ? A + m0 : A + (long)m0 * g.lda;
   const bf16* bbase = B_RED ? B + n0 : B + (long)n0 * g.ldb;
-  const long a_bytes = A_RED ? ((long)(g.K - 1) * g.lda + (g.M - m0)) * 2
-                             : ((long)(min(g.M - m0, BM) - 1) * g.lda + g.K) * 2;
-  const long b_bytes = B_RED ? ((long)(g.K - 1) * g.ldb + (g.N - n0)) * 2
-                             : ((long)(min(g.N - n0, BN) - 1) * g.ldb + g.K) * 2;
+  const long a_bytes = A_RED ? ((long)(g.K - 1) * g.lda + ((g.M - m0 + 1) & ~1)) * 2
+                             : ((long)(min(g.M - m0, BM) - 1) * g.lda + ((g.K + 1) & ~1)) * 2;
+  const long b_bytes = B_RED ? ((long)(g.K - 1) * g.ldb + ((g.N - n0 + 1) & ~1)) * 2
+                             : ((long)(min(g.N - n0, BN) - 1) * g.ldb + ((g.K + 1) & ~1)) * 2;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
       (void*)abase, 0, (int)min(a_bytes, 0x7fffffffL), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
@@ -905,423 +590,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(GemmArgs g) {
 // (K / 2, lda / 2, ldb / 2): the data path is byte-identical to the bf16 kernel.
 __global__ __launch_bounds__(256, 2) void gemm_fp8_v2_kernel(GemmArgs g) {
   v2_body<false, false, 64, 4, true>(g);
-}
-template <bool A_RED, bool B_RED>
-__global__ __launch_bounds__(512, 4) void gemm_bf16_v4_kernel(GemmArgs g) {
-  v2_body<A_RED, B_RED, 64, 8>(g);
-}
-
-// The compiler sometimes loses the wave-uniformity of a tile base pointer (then every
-// buffer_load ... lds becomes a 12-instruction waterfall loop over the descriptor): pin it.
-template <typename T>
-MK_DEV const T* uniform_ptr(const T* p) {
-  const uint64_t v = reinterpret_cast<uint64_t>(p);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return reinterpret_cast<const T*>(((uint64_t)hi << 32) | lo);
-}
-
-// ------------------------------------------------ v3: 256x256 tile, 8 waves of 128x64 --
-// Same issue-lean structure as v2 with twice the MFMA work per barrier and per LDS byte:
-// 8 waves (2 M x 4 N), wave tile 128x64 = 4x2 fragments (128 accumulator registers), LDS
-// 2 x 64 KiB, one workgroup per CU (two waves per SIMD).  Tile-count quantisation on the
-// 256-CU chip is absorbed by the stream-K tail.
-template <bool RED_MAJOR>
-MK_DEV void v3_voffsets(int row0, int R, long ld, int w, int l, int (&voff)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = w + 8 * i;  // 1-KiB piece (of 32) of the 256 x 64 tile
-    if constexpr (!RED_MAJOR) {
-      const int row = p * 8 + (l >> 3);
-      const int kc = (l & 7) ^ ((row >> 1) & 7);
-      const int gr = min(row0 + row, R - 1) - row0;
-      voff[i] = (int)((long)gr * ld * 2 + kc * 16);
-    } else {
-      const int q = p * 64 + l;
-      const int kr = q >> 5, cc = q & 31;
-      const int mc = cc ^ (4 * (kr & 3));
-      voff[i] = (int)((long)kr * ld * 2 + mc * 16);
-    }
-  }
-}
-template <bool RED_MAJOR, int NF>
-MK_DEV void v3_frag_offsets(int wrow0, int l, int (&off)[NF][4]) {
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    if constexpr (!RED_MAJOR) {
-      const int row = wrow0 + f * 32 + (l & 31);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int kc = ks * 2 + (l >> 5);
-        off[f][ks] = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
-      }
-    } else {
-      const int li = l & 15;
-      const int col = wrow0 + f * 32 + 16 * ((l >> 4) & 1) + 4 * (li & 3);
-      const int kr = 8 * (l >> 5) + (li >> 2);
-      off[f][0] = kr * 512 + (((col >> 3) ^ (4 * (kr & 3))) << 4) + ((col & 7) << 1);
-      off[f][1] = off[f][2] = off[f][3] = 0;
-    }
-  }
-}
-
-// STAG = true ("v5"): the two M-halves of the workgroup (waves 0-3 / 4-7, one of each per SIMD)
-// run ONE BARRIER out of phase, at k-step granularity: while one group issues the six
-// ds_read_b128 of its next k-step (and its share of the next tile's LDS-DMA), the other group
-// owns the matrix pipe with its 8 MFMAs.  Lock-step waves (STAG = false) all burst-read 48 KiB
-// of LDS together after each barrier while the MFMA pipe idles, then all contend for it.
-// Hazards by construction: a tile's LDS-DMA is issued >= 1 barrier after every wave retired
-// (lgkmcnt) its reads of that stage, every wave drains vmcnt in the interval BEFORE the barrier
-// that precedes the first read of the new tile, and the loads have >= 3 intervals to land.
-// SCHED = 2 ("v6"): same stagger, but the A operand has THREE 32-KiB LDS slots and B two
-// (160 KiB): A is prefetched two tiles ahead, so the eight LDS-DMA instructions a wave issues per
-// tile are spread two per k-step over ALL four k-steps (an LDS-DMA issue costs the wave 60-180
-// cycles; four in one k-step made that step twice as long as the MFMA group it has to hide
-// under) and still have >= 3 barrier intervals to land; the end-of-tile wait is a counted
-// vmcnt(2) that leaves the just-issued A pieces in flight.
-template <bool A_RED, bool B_RED, int SCHED>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g) {
-  constexpr bool STAG = SCHED == 1;
-  constexpr int BM3 = 256, BN3 = 256, FM = 4, FN = 2;
-  constexpr int A_BYTES = BM3 * 128, STAGE = 2 * A_BYTES;  // 64 KiB per stage
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int tm, tn;
-  int piece = -1, tail_idx = 0;
-  int kt_begin = 0, kt_end = g.K / BK;
-  {
-    const int bid = blockIdx.x;
-    if (bid < g.dp_tiles) {
-      tile_from_index(xcd_remap(bid, g.dp_tiles), g.tiles_m, g.tiles_n, tm, tn, 8);
-    } else {
-      const int r = bid - g.dp_tiles;
-      tail_idx = r / g.split;
-      piece = r - tail_idx * g.split;
-      tile_from_index(g.dp_tiles + tail_idx, g.tiles_m, g.tiles_n, tm, tn, 8);
-      kt_begin = piece * g.kt_per_piece;
-      kt_end = min(kt_end, kt_begin + g.kt_per_piece);
-    }
-  }
-  const int z = blockIdx.z, z1 = z / g.nb2, z2 = z - z1 * g.nb2;
-  const bf16* A = reinterpret_cast<const bf16*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
-  const bf16* B = reinterpret_cast<const bf16*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
-  bf16* C = reinterpret_cast<bf16*>(g.C) + z1 * g.sC1 + z2 * g.sC2;
-  const bf16* Rp = g.R ? reinterpret_cast<const bf16*>(g.R) + z1 * g.sR1 + z2 * g.sR2 : nullptr;
-  const int m0 = tm * BM3, n0 = tn * BN3;
-  const int l = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm0 = (w >> 2) * 128, wn0 = (w & 3) * 64;
-
-  const bf16* abase = uniform_ptr(A_RED ? A + m0 : A + (long)m0 * g.lda);
-  const bf16* bbase = uniform_ptr(B_RED ? B + n0 : B + (long)n0 * g.ldb);
-  const long a_bytes = A_RED ? ((long)(g.K - 1) * g.lda + (g.M - m0)) * 2
-                             : ((long)(min(g.M - m0, BM3) - 1) * g.lda + g.K) * 2;
-  const long b_bytes = B_RED ? ((long)(g.K - 1) * g.ldb + (g.N - n0)) * 2
-                             : ((long)(min(g.N - n0, BN3) - 1) * g.ldb + g.K) * 2;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)abase, 0, (int)min(a_bytes, 0x7fffffffL), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)bbase, 0, (int)min(b_bytes, 0x7fffffffL), 0x00020000);
-  int voffA[4], voffB[4];
-  v3_voffsets<A_RED>(m0, g.M, g.lda, w, l, voffA);
-  v3_voffsets<B_RED>(n0, g.N, g.ldb, w, l, voffB);
-  const int stepA = A_RED ? (int)(BK * g.lda * 2) : BK * 2;
-  const int stepB = B_RED ? (int)(BK * g.ldb * 2) : BK * 2;
-  int offA[FM][4], offB[FN][4];
-  v3_frag_offsets<A_RED, FM>(wm0, l, offA);
-  v3_frag_offsets<B_RED, FN>(wn0, l, offB);
-
-  f32x16 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  int sA = kt_begin * stepA, sB = kt_begin * stepB;
-  // one quarter of the next tile's LDS-DMA (1 A piece + 1 B piece per wave); the four quarters
-  // are interleaved with the four MFMA groups of the current tile so that the wave is never
-  // stuck issuing eight VMEM instructions back to back (ablation: the burst cost ~30 %).
-  auto issue_part = [&](int stage, int i) {
-    if (g.ablate & 1) return;
-    char* la = smem + stage * STAGE + w * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        rsA, (__attribute__((address_space(3))) void*)(la + i * 8192), 16, voffA[i], sA, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        rsB, (__attribute__((address_space(3))) void*)(la + A_BYTES + i * 8192), 16, voffB[i], sB, 0,
-        0);
-    if (i == 3) { sA += stepA; sB += stepB; }
-  };
-  auto issue = [&](int stage) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) issue_part(stage, i);
-  };
-#define MK_V3_FRAG(RED, OFF, F, KS, BASE)                                                        \
-  [&]() -> bf16x8 {                                                                              \
-    if constexpr (!(RED)) {                                                                      \
-      return *reinterpret_cast<const bf16x8*>(smem + (BASE) + OFF[F][KS]);                       \
-    } else {                                                                                     \
-      bf16x8 o_;                                                                                 \
-      bf16x4 t0_ = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                     \
-          (__attribute__((address_space(3))) bf16x4*)(smem + (BASE) + (KS) * 16 * 512 + OFF[F][0])); \
-      bf16x4 t1_ = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                     \
-          (__attribute__((address_space(3))) bf16x4*)(smem + (BASE) + ((KS) * 16 + 4) * 512 + OFF[F][0])); \
-      o_[0] = t0_[0]; o_[1] = t0_[1]; o_[2] = t0_[2]; o_[3] = t0_[3];                            \
-      o_[4] = t1_[0]; o_[5] = t1_[1]; o_[6] = t1_[2]; o_[7] = t1_[3];                            \
-      return o_;                                                                                 \
-    }                                                                                            \
-  }()
-#define MK_V3_LOAD(DST, KS, STAGE_)                                                              \
-  do {                                                                                           \
-    DST[0] = MK_V3_FRAG(A_RED, offA, 0, KS, (STAGE_) * STAGE);                                   \
-    DST[1] = MK_V3_FRAG(A_RED, offA, 1, KS, (STAGE_) * STAGE);                                   \
-    DST[2] = MK_V3_FRAG(A_RED, offA, 2, KS, (STAGE_) * STAGE);                                   \
-    DST[3] = MK_V3_FRAG(A_RED, offA, 3, KS, (STAGE_) * STAGE);                                   \
-    DST[4] = MK_V3_FRAG(B_RED, offB, 0, KS, (STAGE_) * STAGE + A_BYTES);                         \
-    DST[5] = MK_V3_FRAG(B_RED, offB, 1, KS, (STAGE_) * STAGE + A_BYTES);                         \
-  } while (0)
-#define MK_V3_MFMA(F)                                                                            \
-  do {                                                                                           \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                           \
-      acc[i_][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[4], F[i_], acc[i_][0], 0, 0, 0);    \
-      acc[i_][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[5], F[i_], acc[i_][1], 0, 0, 0);    \
-    }                                                                                            \
-  } while (0)
-#define MK_V3_COMPUTE(STAGE_, NEXT_)                                                             \
-  do {                                                                                           \
-    bf16x8 fa_[6], fb_[6];                                                                       \
-    MK_V3_LOAD(fa_, 0, STAGE_);                                                                  \
-    MK_V3_LOAD(fb_, 1, STAGE_);                                                                  \
-    if (NEXT_) issue_part(1 - (STAGE_), 0);                                                      \
-    MK_V3_MFMA(fa_);                                                                             \
-    MK_V3_LOAD(fa_, 2, STAGE_);                                                                  \
-    if (NEXT_) issue_part(1 - (STAGE_), 1);                                                      \
-    MK_V3_MFMA(fb_);                                                                             \
-    MK_V3_LOAD(fb_, 3, STAGE_);                                                                  \
-    if (NEXT_) issue_part(1 - (STAGE_), 2);                                                      \
-    MK_V3_MFMA(fa_);                                                                             \
-    if (NEXT_) issue_part(1 - (STAGE_), 3);                                                      \
-    MK_V3_MFMA(fb_);                                                                             \
-  } while (0)
-#define MK_V3_SYNC()                                          \
-  do {                                                        \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          \
-    if (!(g.ablate & 2)) __builtin_amdgcn_s_barrier();        \
-    asm volatile("" ::: "memory");                            \
-  } while (0)
-
-  const int nk = kt_end - kt_begin;
-  if constexpr (SCHED == 2) {
-    constexpr int B_BASE = 3 * A_BYTES;
-    const int grp = w >> 2;
-    int gA = kt_begin * stepA, gB = kt_begin * stepB;   // global byte offsets of the next A / B tile to load
-    auto load_a = [&](int slot, int i) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsA, (__attribute__((address_space(3))) void*)(smem + slot * A_BYTES + w * 1024 + i * 8192), 16,
-          voffA[i], gA, 0, 0);
-    };
-    auto load_b = [&](int slot, int i) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsB, (__attribute__((address_space(3))) void*)(smem + B_BASE + slot * A_BYTES + w * 1024 + i * 8192),
-          16, voffB[i], gB, 0, 0);
-    };
-#define MK_V6_BAR()                            \
-  do {                                         \
-    __builtin_amdgcn_sched_barrier(0);         \
-    __builtin_amdgcn_s_barrier();              \
-    __builtin_amdgcn_sched_barrier(0);         \
-  } while (0)
-    // prologue: A(0), B(0), A(1)
-    if (nk > 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) load_a(0, i);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) load_b(0, i);
-      gA += stepA; gB += stepB;
-      if (nk > 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) load_a(1, i);
-        gA += stepA;
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MK_V6_BAR();
-    if (grp == 1) MK_V6_BAR();
-    int sa = 0, sb = 0;        // slots of the tile being computed
-    int sa2 = 2, sb1 = 1;      // slots the prefetches of this tile go to: A(t+2), B(t+1)
-#define MK_V6_STEP(KS)                                                                           \
-  do {                                                                                           \
-    bf16x8 fr_[6];                                                                               \
-    fr_[0] = MK_V3_FRAG(A_RED, offA, 0, KS, abase_lds);                                          \
-    fr_[1] = MK_V3_FRAG(A_RED, offA, 1, KS, abase_lds);                                          \
-    fr_[2] = MK_V3_FRAG(A_RED, offA, 2, KS, abase_lds);                                          \
-    fr_[3] = MK_V3_FRAG(A_RED, offA, 3, KS, abase_lds);                                          \
-    fr_[4] = MK_V3_FRAG(B_RED, offB, 0, KS, bbase_lds);                                          \
-    fr_[5] = MK_V3_FRAG(B_RED, offB, 1, KS, bbase_lds);                                          \
-    if (grp == 0) {                                                                              \
-      if ((KS) == 0 && has_a) { load_a(sa2, 0); load_a(sa2, 1); }                                \
-      if ((KS) == 1 && has_b) { load_b(sb1, 0); load_b(sb1, 1); }                                \
-      if ((KS) == 2 && has_b) { load_b(sb1, 2); load_b(sb1, 3); }                                \
-      if ((KS) == 3 && has_a) { load_a(sa2, 2); load_a(sa2, 3); }                                \
-    } else {                                                                                     \
-      if ((KS) == 0 && has_b) { load_b(sb1, 0); load_b(sb1, 1); }                                \
-      if ((KS) == 1 && has_b) { load_b(sb1, 2); load_b(sb1, 3); }                                \
-      if ((KS) == 2 && has_a) { load_a(sa2, 0); load_a(sa2, 1); }                                \
-      if ((KS) == 3 && has_a) { load_a(sa2, 2); load_a(sa2, 3); }                                \
-      if ((KS) == 3) {                                                                           \
-        if (has_a) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                              \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
-      }                                                                                          \
-    }                                                                                            \
-    MK_V6_BAR();                                                                                 \
-    __builtin_amdgcn_s_setprio(1);                                                               \
-    MK_V3_MFMA(fr_);                                                                             \
-    __builtin_amdgcn_s_setprio(0);                                                               \
-    if (grp == 0 && (KS) == 3) {                                                                 \
-      if (has_a) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                \
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
-    }                                                                                            \
-    MK_V6_BAR();                                                                                 \
-  } while (0)
-#pragma unroll 1
-    for (int kt = 0; kt < nk; ++kt) {
-      const bool has_b = kt + 1 < nk, has_a = kt + 2 < nk;
-      const int abase_lds = sa * A_BYTES, bbase_lds = B_BASE + sb * A_BYTES;
-      MK_V6_STEP(0);
-      MK_V6_STEP(1);
-      MK_V6_STEP(2);
-      MK_V6_STEP(3);
-      gA += stepA; gB += stepB;
-      sa = sa == 2 ? 0 : sa + 1;
-      sa2 = sa2 == 2 ? 0 : sa2 + 1;
-      sb ^= 1; sb1 ^= 1;
-    }
-    if (grp == 0) MK_V6_BAR();
-#undef MK_V6_STEP
-#undef MK_V6_BAR
-  } else if constexpr (STAG) {
-    if (nk > 0) issue(0);
-#define MK_V5_BAR()                            \
-  do {                                         \
-    __builtin_amdgcn_sched_barrier(0);         \
-    __builtin_amdgcn_s_barrier();              \
-    __builtin_amdgcn_sched_barrier(0);         \
-  } while (0)
-// one k-step of one wave: L segment | barrier | M segment | barrier
-#define MK_V5_STEP(KS, STAGE_, NEXT_)                                                            \
-  do {                                                                                           \
-    bf16x8 fr_[6];                                                                               \
-    MK_V3_LOAD(fr_, KS, STAGE_);                                                                 \
-    if (NEXT_) {                                                                                 \
-      if (grp == 0 && (KS) == 1) { issue_part(1 - (STAGE_), 0); issue_part(1 - (STAGE_), 1); }   \
-      if (grp == 0 && (KS) == 2) { issue_part(1 - (STAGE_), 2); issue_part(1 - (STAGE_), 3); }   \
-      if (grp == 1 && (KS) == 0) { issue_part(1 - (STAGE_), 0); issue_part(1 - (STAGE_), 1); }   \
-      if (grp == 1 && (KS) == 1) { issue_part(1 - (STAGE_), 2); issue_part(1 - (STAGE_), 3); }   \
-    }                                                                                            \
-    if (grp == 1 && (KS) == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
-    MK_V5_BAR();                                                                                 \
-    __builtin_amdgcn_s_setprio(1);                                                               \
-    MK_V3_MFMA(fr_);                                                                             \
-    __builtin_amdgcn_s_setprio(0);                                                               \
-    if (grp == 0 && (KS) == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  \
-    MK_V5_BAR();                                                                                 \
-  } while (0)
-#define MK_V5_TILE(STAGE_, NEXT_)    \
-  do {                               \
-    MK_V5_STEP(0, STAGE_, NEXT_);    \
-    MK_V5_STEP(1, STAGE_, NEXT_);    \
-    MK_V5_STEP(2, STAGE_, NEXT_);    \
-    MK_V5_STEP(3, STAGE_, NEXT_);    \
-  } while (0)
-    const int grp = w >> 2;  // wave-uniform (SGPR): M half of the tile = stagger group
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MK_V5_BAR();             // tile 0 landed and visible
-    if (grp == 1) MK_V5_BAR();
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-      MK_V5_TILE(0, true);
-      MK_V5_TILE(1, kt + 2 < nk);
-    }
-    if (kt < nk) MK_V5_TILE(0, false);
-    if (grp == 0) MK_V5_BAR();
-#undef MK_V5_TILE
-#undef MK_V5_STEP
-#undef MK_V5_BAR
-  } else {
-  if (nk > 0) issue(0);
-  int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    MK_V3_SYNC();
-    MK_V3_COMPUTE(0, true);
-    MK_V3_SYNC();
-    MK_V3_COMPUTE(1, kt + 2 < nk);
-  }
-  if (kt < nk) {
-    MK_V3_SYNC();
-    MK_V3_COMPUTE(0, false);
-  }
-  }
-#undef MK_V3_SYNC
-#undef MK_V3_COMPUTE
-#undef MK_V3_MFMA
-#undef MK_V3_LOAD
-#undef MK_V3_FRAG
-  if (piece >= 0) {
-    // stream-K tail, same protocol as v2 (write-through slabs, counter, one acquire)
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int SLAB = FM * FN * 16 * 512;  // floats per piece
-    float* slab0 = g.ws + (long)tail_idx * g.split * SLAB;
-    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(slab0 + (long)piece * SLAB), 0, SLAB * 4, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int e = (i * FN + j) * 4 + q4;
-          u32x4 v;
-          v[0] = __float_as_uint(acc[i][j][4 * q4]); v[1] = __float_as_uint(acc[i][j][4 * q4 + 1]);
-          v[2] = __float_as_uint(acc[i][j][4 * q4 + 2]); v[3] = __float_as_uint(acc[i][j][4 * q4 + 3]);
-          __builtin_amdgcn_raw_buffer_store_b128(v, rsS, (e * 512 + (int)threadIdx.x) * 16, 0, 16);
-        }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int* flag = reinterpret_cast<int*>(smem);
-    if (threadIdx.x == 0) {
-      const int old = __hip_atomic_fetch_add(g.counters + tail_idx, 1, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT);
-      *flag = (old == g.split - 1);
-    }
-    __syncthreads();
-    if (!*flag) return;
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      g.counters[tail_idx] = 0;   // self-cleaning: the next launch on this stream finds zeros
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    for (int pc = 0; pc < g.split; ++pc) {
-      const float* sl = slab0 + (long)pc * SLAB;
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const int e = (i * FN + j) * 4 + q4;
-            const float4 v = *reinterpret_cast<const float4*>(sl + ((long)e * 512 + threadIdx.x) * 4);
-            acc[i][j][4 * q4] += v.x; acc[i][j][4 * q4 + 1] += v.y;
-            acc[i][j][4 * q4 + 2] += v.z; acc[i][j][4 * q4 + 3] += v.w;
-          }
-    }
-  }
-  wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0, smem);
 }
 
 // ------------------------------------------------ skinny M (decode step) --
@@ -1573,6 +841,50 @@ extern "C" int mk_prof_report(const char* path) {
   return MK_OK;
 }
 
+namespace { int g_force_cfg = -1; }
+// tuning / A-B hook (scripts/gemm_bench.cpp, tests): force a kernel configuration for the
+// following mk_gemm calls of this process (-1 = automatic choice); same meaning as MK_GEMM_CFG
+extern "C" int mk_gemm_set_cfg(int cfg) { g_force_cfg = cfg; return MK_OK; }
+
+namespace mkg {
+int launch_v7(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st);  // gemm_v7.hip
+}
+namespace {
+// Default kernel choice: a small cost model fitted to scripts/gemm_bench.cpp measurements on
+// MI355X (profiles/r02_gemm_shapes.csv; microseconds).  v7: one 256x256 tile per CU and round,
+// (K-tiles x a7 + prologue/epilogue) per round, the last partial round as 128x128 sub-tiles when
+// that is at most two sub-rounds.  v2: 128x128 tiles, two workgroups per CU (four with BK = 32 for
+// reduction-major x reduction-major), fractional rounds through its K-split tail.
+int pick_cfg(const mk_gemm_desc* d, int nbatch, bool v7_ok, int n_cus) {
+  static const bool no_v7 = getenv("MK_GEMM_NO_V7") != nullptr;
+  if (!v7_ok || no_v7 || nbatch != 1) return MK_GEMM_DEFAULT_CFG;
+  const int layout = (d->a_red_major ? 2 : 0) + (d->b_red_major ? 1 : 0);
+  const double nk = (d->K + 63) / 64;
+  const long T7 = (long)mk_cdiv(d->M, 256) * mk_cdiv(d->N, 256);
+  const long full = T7 / n_cus, R = T7 % n_cus;
+  const double a7 = layout == 3 ? 1.68 : layout == 1 ? 1.58 : layout == 2 ? 1.62 : 1.54;
+  const double tile7 = nk * a7 + 14.0, sub7 = nk * 0.48 + 7.0;
+  double t7 = full * tile7;
+  // (a partially filled round of whole tiles runs faster per K-tile: less L2 / power contention)
+  if (R > 0) t7 += (4 * R <= 2 * n_cus) ? (double)mk_cdiv((int)(4 * R), n_cus) * sub7
+                                         : nk * a7 * (0.55 + 0.45 * R / n_cus) + 14.0;
+  const long T2 = (long)mk_cdiv(d->M, 128) * mk_cdiv(d->N, 128);
+  const long slots2 = (long)n_cus * (layout == 3 ? 4 : 2);
+  const double tile2 = layout == 3 ? nk * 1.77 + 8.0 : nk * (layout == 0 ? 0.92 : 1.03) + 5.0;
+  double rounds2 = (double)T2 / slots2;
+  if (rounds2 < 0.25) rounds2 = 0.25;
+  double t2 = rounds2 * tile2;
+  if (const long R2 = T2 % slots2) {   // K-split tail: pieces + the last arriver reading `sp` slabs
+    double sp = (double)slots2 / R2;
+    const double nk2 = layout == 3 ? 2 * nk : nk;
+    if (sp > nk2 / 2) sp = nk2 / 2;
+    if (sp > 64) sp = 64;
+    t2 += 4.0 + 0.65 * sp;
+  }
+  return t7 * 0.95 < t2 ? 11 : MK_GEMM_DEFAULT_CFG;   // (ties go to v7: the model is pessimistic for it)
+}
+}  // namespace
+
 extern "C" int mk_abi_version(void) { return MK_ABI_VERSION; }
 
 extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
@@ -1631,41 +943,55 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     return mk_check_launch();
   }
   if (d->dtype == MK_BF16) {
-    // kernel configuration: 5 = v2 issue-lean LDS-DMA 128x128 (needs aligned operands, K%64==0),
-    // 0 = register-staged 128x128 (2 LDS buffers), 1 = LDS-DMA 128x128 x2,
-    // 2 = LDS-DMA 128x128 x3 stages, 3 = LDS-DMA 256x128 x2, 4 = LDS-DMA 256x128 x3 stages.
-    static const int env_cfg = [] {
+    // kernel configuration: 11 = v7 256x256 quadrant-phase LDS-DMA ring (gemm_v7.hip; big aligned
+    // problems), 5 = v2 issue-lean LDS-DMA 128x128 (aligned operands, K % 64 == 0), 7 = v2 with
+    // BK = 32 (reduction-major x reduction-major), 0 = register-staged 128x128 (anything).
+    // MK_GEMM_CFG forces one where it is legal.
+    static const int env_cfg0 = [] {
       const char* e = getenv("MK_GEMM_CFG");
       return e ? atoi(e) : -1;
     }();
-    int cfg = env_cfg >= 0 ? env_cfg : MK_GEMM_DEFAULT_CFG;
-    if (fp8) cfg = 5;
+    const int env_cfg = g_force_cfg >= 0 ? g_force_cfg : env_cfg0;
     const auto fits = [&](bool red, long ld, int rows) {
       const long span = red ? (long)d->K * ld * 2 : ((long)rows * ld + d->K) * 2;
       return span < 0x7fffffffL;
     };
+    // a K that is not a multiple of the K-tile: rows >= K of a reduction-major operand lie outside
+    // its buffer descriptor and load as zeros; a K-major operand must then be zero-padded (flags)
+    const long kpad = (d->K + 63) / 64 * 64;
+    const bool ktail_a = d->a_red_major || ((d->flags & MK_GEMM_A_KPAD_ZERO) && d->lda >= kpad);
+    const bool ktail_b = d->b_red_major || ((d->flags & MK_GEMM_B_KPAD_ZERO) && d->ldb >= kpad);
     const bool v2_ok = aligned16(d->A) && aligned16(d->B) && (d->lda % 8 == 0) && (d->ldb % 8 == 0) &&
                        (d->sA1 % 8 == 0) && (d->sA2 % 8 == 0) && (d->sB1 % 8 == 0) &&
                        (d->sB2 % 8 == 0) &&
-                       (d->K % BK == 0 || (d->a_red_major && d->b_red_major && d->K > BK)) &&
+                       (d->K % BK == 0 || (ktail_a && ktail_b && d->K > BK)) &&
                        fits(d->a_red_major, d->lda, BM) && fits(d->b_red_major, d->ldb, BN);
-    if (cfg == 6 || cfg == 9 || cfg == 10) {  // 256x256 tiles only pay for big problems; otherwise the 128x128 v2 kernel
-      const bool big = d->M >= 512 && d->N >= 512 && d->K >= 512 && nbatch == 1 && d->ws &&
+    const bool v7_ok = v2_ok && !fp8 && d->K >= 128 && d->M > 128 && d->N > 128 &&
                        fits(d->a_red_major, d->lda, 256) && fits(d->b_red_major, d->ldb, 256);
-      if (!big) cfg = 5;
-    }
-    if ((cfg == 6 || cfg == 9 || cfg == 10) && d->K % BK) cfg = 5;   // only the v2 body handles a reduction tail
+    static const int n_cus = [] {
+      int dev = 0, cus = 256;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      return cus;
+    }();
+    int cfg;
+    if (fp8) cfg = 5;
+    else if (env_cfg >= 0) cfg = env_cfg;
+    else cfg = pick_cfg(d, nbatch, v7_ok, n_cus);
+    int v7_var = 0;   // cfg 20 + VAR: experimental v7 schedules (only in MK_V7_EXPERIMENTS builds)
+    if (cfg >= 20) { v7_var = cfg - 20; cfg = 11; }
+    if (cfg == 11 && !v7_ok) cfg = 5;
+    if (cfg != 0 && cfg != 5 && cfg != 7 && cfg != 11) cfg = 5;
     if (cfg >= 5 && !v2_ok) cfg = 0;
     if (fp8 && cfg != 5) return MK_ERR_UNSUPPORTED;
     // Measured (profiles/): with BOTH operands reduction-major (dW = dy^T x) the global rows are
     // whole 256-B lines whatever BK is, and BK = 32 (32 KiB LDS -> 4 workgroups per CU) is 17 %
-    // faster (1090-1140 vs 930-980 TFLOP/s); K-major operands would degrade to 64-B segments.
+    // faster than BK = 64 on the 128x128 tile; K-major operands would degrade to 64-B segments.
     if (cfg == 5 && d->a_red_major && d->b_red_major && !getenv("MK_GEMM_NO_BK32")) cfg = 7;
     const int bkv = cfg == 7 ? 32 : BK;
     rec.cfg = cfg;
-    if ((cfg == 3 || cfg == 4) && (d->M <= 128 || (long)mk_cdiv(d->M, 256) * mk_cdiv(d->N, BN) * nbatch < 256)) cfg -= 2;
-    const bool t256 = cfg == 6 || cfg == 9 || cfg == 10;
-    const int bm = (cfg == 3 || cfg == 4 || t256) ? 256 : 128;
+    const bool t256 = cfg == 11;
+    const int bm = t256 ? 256 : 128;
     const int bn = t256 ? 256 : BN;
     g.tiles_m = mk_cdiv(d->M, bm);
     g.tiles_n = mk_cdiv(d->N, bn);
@@ -1675,7 +1001,6 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
               (d->sC1 % 4 == 0) && (d->sC2 % 4 == 0) &&
               (!d->R || (((reinterpret_cast<uintptr_t>(d->R) & 7) == 0) && (d->ldr % 4 == 0) &&
                          (d->sR1 % 4 == 0) && (d->sR2 % 4 == 0)));
-    static const int lds_pad = [] { const char* e = getenv("MK_GEMM_LDS_PAD"); return e ? atoi(e) : 0; }();
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch);
     g.dp_tiles = g.tiles_m * g.tiles_n;
     g.lin_batch = 0;
@@ -1683,24 +1008,25 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     g.kt_per_piece = 0;
     g.ws = nullptr;
     g.counters = nullptr;
-    static const int ablate = [] { const char* e = getenv("MK_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
-    g.ablate = ablate;
-    static const int n_cus = [] {
-      int dev = 0, cus = 256;
-      (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      return cus;
-    }();
-    // resident workgroups per CU of the chosen kernel (a function-local static here used to
-    // freeze the factor of whichever configuration happened to launch first)
+    g.ablate = v7_var;
+    // resident workgroups per CU of the chosen kernel
     const int slots = n_cus * (t256 ? 1 : (cfg == 7 ? 4 : 2));
-    if ((cfg == 5 || cfg == 7 || cfg == 8 || (t256 && nbatch == 1)) && d->ws && !getenv("MK_GEMM_NO_STREAMK")) {
+    static const bool no_streamk = getenv("MK_GEMM_NO_STREAMK") != nullptr;
+    if (t256 && !no_streamk) {
+      // v7: the last partial round of 256x256 tiles is computed as four 128x128 sub-tiles each
+      // (one workgroup per sub-tile, full K, no partial sums) when that takes fewer rounds
+      const int T = g.tiles_m * g.tiles_n, R = T % n_cus;
+      if (R > 0 && 4 * R <= 2 * n_cus) {
+        g.dp_tiles = T - R;
+        grid.x = g.dp_tiles + 4 * R;
+      }
+    } else if ((cfg == 5 || cfg == 7) && d->ws && !no_streamk) {
       const int T = g.tiles_m * g.tiles_n * nbatch, nkt = (d->K + bkv - 1) / bkv;
       const int R = T % slots;
       int sp = R > 0 ? slots / R : 1;
       if (sp > nkt / 2) sp = nkt / 2;  // at least two K-tiles per piece
       if (sp > 64) sp = 64;
-      const long need = 4096 + (long)R * sp * (t256 ? 128 * 512 : 64 * 256) * 4;
+      const long need = 4096 + (long)R * sp * (64 * 256) * 4;
       if (R > 0 && sp >= 2 && need <= d->ws_bytes) {
         g.dp_tiles = T - R;
         g.split = sp;
@@ -1715,18 +1041,6 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
         }
       }
     }
-#define MK_PIPE(AR, BR, BMV, ST)                                                              \
-  do {                                                                                        \
-    constexpr int shm_ = (BMV * 128 + BN * 128) * ST;                                         \
-    static bool attr_done = false;                                                            \
-    if (!attr_done) {                                                                         \
-      (void)hipFuncSetAttribute(                                                              \
-          reinterpret_cast<const void*>(&gemm_bf16_pipe_kernel<AR, BR, BMV, ST>),             \
-          hipFuncAttributeMaxDynamicSharedMemorySize, shm_);                                  \
-      attr_done = true;                                                                       \
-    }                                                                                         \
-    MK_LAUNCH((gemm_bf16_pipe_kernel<AR, BR, BMV, ST>), grid, dim3(BMV * 2), shm_, st, g);    \
-  } while (0)
 #define MK_REG(AR, BR)                                                                        \
   do {                                                                                        \
     static bool attr_done = false;                                                            \
@@ -1742,10 +1056,10 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     static bool attr_done = false;                                                            \
     if (!attr_done) {                                                                         \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v2_kernel<AR, BR, 64>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + lds_pad); \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);  \
       attr_done = true;                                                                       \
     }                                                                                         \
-    MK_LAUNCH((gemm_bf16_v2_kernel<AR, BR, 64>), grid, dim3(256), 4 * TILE_BYTES + lds_pad, st, g); \
+    MK_LAUNCH((gemm_bf16_v2_kernel<AR, BR, 64>), grid, dim3(256), 4 * TILE_BYTES, st, g);     \
   } while (0)
 #define MK_V2F8()                                                                             \
   do {                                                                                        \
@@ -1759,60 +1073,17 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
   } while (0)
 #define MK_V2S(AR, BR)                                                                        \
   MK_LAUNCH((gemm_bf16_v2_kernel<AR, BR, 32>), grid, dim3(256), 2 * TILE_BYTES, st, g)
-#define MK_V4(AR, BR)                                                                         \
-  do {                                                                                        \
-    static bool attr_done = false;                                                            \
-    if (!attr_done) {                                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v4_kernel<AR, BR>),  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);  \
-      attr_done = true;                                                                       \
-    }                                                                                         \
-    MK_LAUNCH((gemm_bf16_v4_kernel<AR, BR>), grid, dim3(512), 4 * TILE_BYTES, st, g);         \
-  } while (0)
-#define MK_V3(AR, BR)                                                                         \
-  do {                                                                                        \
-    static bool attr_done = false;                                                            \
-    if (!attr_done) {                                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v3_kernel<AR, BR, 0>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 131072);          \
-      attr_done = true;                                                                       \
-    }                                                                                         \
-    MK_LAUNCH((gemm_bf16_v3_kernel<AR, BR, 0>), grid, dim3(512), 131072, st, g);          \
-  } while (0)
-#define MK_V5(AR, BR)                                                                         \
-  do {                                                                                        \
-    static bool attr_done = false;                                                            \
-    if (!attr_done) {                                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v3_kernel<AR, BR, 1>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 131072);          \
-      attr_done = true;                                                                       \
-    }                                                                                         \
-    MK_LAUNCH((gemm_bf16_v3_kernel<AR, BR, 1>), grid, dim3(512), 131072, st, g);           \
-  } while (0)
-#define MK_V6(AR, BR)                                                                         \
-  do {                                                                                        \
-    static bool attr_done = false;                                                            \
-    if (!attr_done) {                                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v3_kernel<AR, BR, 2>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 163840);          \
-      attr_done = true;                                                                       \
-    }                                                                                         \
-    MK_LAUNCH((gemm_bf16_v3_kernel<AR, BR, 2>), grid, dim3(512), 163840, st, g);              \
-  } while (0)
 #define MK_LAYOUT(AR, BR)                                    \
   do {                                                       \
     if (cfg == 7) MK_V2S(AR, BR);                            \
-    else if (cfg == 8) MK_V4(AR, BR);                        \
-    else if (cfg == 6) MK_V3(AR, BR);                        \
-    else if (cfg == 9) MK_V5(AR, BR);                        \
-    else if (cfg == 10) MK_V6(AR, BR);                       \
     else if (cfg == 5) MK_V2(AR, BR);                        \
-    else if (cfg == 0) MK_REG(AR, BR);                       \
-    else if (cfg == 1) MK_PIPE(AR, BR, 128, 2);              \
-    else if (cfg == 2) MK_PIPE(AR, BR, 128, 3);              \
-    else if (cfg == 3) MK_PIPE(AR, BR, 256, 2);              \
-    else MK_PIPE(AR, BR, 256, 3);                            \
+    else MK_REG(AR, BR);                                     \
   } while (0)
+    if (t256) {
+      const int rc = mkg::launch_v7(g, d->a_red_major != 0, d->b_red_major != 0, grid, st);
+      if (g_prof_on) { (void)hipEventRecord(rec.b, st); g_prof.push_back(rec); }
+      return rc;
+    }
     if (fp8) MK_V2F8();
     else if (!d->a_red_major && !d->b_red_major) MK_LAYOUT(false, false);
     else if (!d->a_red_major && d->b_red_major) MK_LAYOUT(false, true);
@@ -1822,12 +1093,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
 #undef MK_V2
 #undef MK_V2S
 #undef MK_V2F8
-#undef MK_V4
-#undef MK_V3
-#undef MK_V5
-#undef MK_V6
 #undef MK_REG
-#undef MK_PIPE
   } else {
     g.tiles_m = mk_cdiv(d->M, FBM);
     g.tiles_n = mk_cdiv(d->N, FBN);

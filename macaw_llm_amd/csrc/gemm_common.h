@@ -1,0 +1,182 @@
+// Shared pieces of the GEMM kernels (gemm.hip, gemm_v7.hip): launch arguments, tile order,
+// activation and the LDS-transposed accumulator epilogue.
+#pragma once
+#include "common.h"
+#include "../../include/macaw_hip.h"
+
+namespace mkg {
+
+struct GemmArgs {
+  const void* A; const void* B; void* C; const void* R; const void* bias;
+  int M, N, K;
+  long lda, ldb, ldc, ldr;
+  int nb2;
+  long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
+  float alpha;
+  const float* scale_a; const float* scale_b;  // optional device scalars multiplied into alpha (fp8)
+  int bias_mode, act, accumulate;
+  int tiles_m, tiles_n;
+  int a_vec, b_vec;  // 1: 16-byte aligned vector loads allowed
+  int c_vec;         // 1: vector C/R access allowed
+  // stream-K tail (v2 kernel only): blocks [0, dp_tiles) own whole tiles; the remaining
+  // tiles are cut into `split` K-pieces of `kt_per_piece` K-tiles, one block each.
+  int dp_tiles, split, kt_per_piece;
+  int lin_batch;   // 1: batch index is folded into the linear tile index (grid.z == 1)
+  int ablate;      // debug only (MK_GEMM_ABLATE): 1 = skip global->LDS, 2 = skip barrier wait
+  float* ws;       // fp32 slabs [tail tile][piece][64 regs][256 threads]
+  int* counters;   // arrival counter per tail tile (zeroed by the launcher)
+};
+
+MK_DEV float apply_act(float v, int act) {
+  if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  if (act == 2) return v / (1.0f + __expf(-1.702f * v));
+  return v;
+}
+
+// XCD-aware + grouped tile order (cdna_hip_programming.md T1, bijective form).
+MK_DEV int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+MK_DEV void tile_from_index(int wg, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M);
+MK_DEV void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  tile_from_index(xcd_remap(bid, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn, 8);
+}
+MK_DEV void tile_from_index(int wg, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M = 8) {
+  const int per_group = GROUP_M * tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(tiles_m - first_m, GROUP_M);
+  const int in_g = wg - group * per_group;
+  tm = first_m + in_g % gsize;
+  tn = in_g / gsize;
+}
+
+// Epilogue for one wave's 64x64 accumulator block (2x2 fragments of 32x32).
+// D[i = n][j = m]: lane holds m = l&31, n = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+//
+// The accumulator layout gives a lane ONE output row and 4-column groups 8 apart: written
+// straight to C that is 16 B per row per instruction (32 different lines each), and a residual /
+// bias read in that layout sat in a conditional block per group -- sixteen serialised HBM round
+// trips per wave tile (an epilogue with bias + residual cost 15-50 % of a K <= 1024 GEMM).  So the
+// tile is transposed through LDS (free after the K loop): each wave stages 32 rows x (FN * 32)
+// fp32 in its private 8 KiB (float4 index XOR row: conflict-free both ways), reads them back
+// row-major -- 16 lanes per 64-column row -- and every load / store is a full 128-byte line per
+// row; the residual rows of a pass group are all requested before the first is used.
+template <int FM, int FN>
+MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* C, const bf16* Rp,
+                          int m0, int n0, int wm0, int wn0, char* smem) {
+  constexpr int W4 = FN * 8;        // float4 per staged row
+  constexpr int RPI = 64 / W4;      // rows per pass
+  constexpr int NPASS = 32 / RPI;   // passes per 32-row fragment
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float alpha = g.alpha;
+  if (g.scale_a) alpha *= g.scale_a[0];
+  if (g.scale_b) alpha *= g.scale_b[0];
+  __syncthreads();                  // every wave is done with the operand tiles in LDS
+  float* buf = reinterpret_cast<float*>(smem) + w * 2048;
+  const int srow = l & 31, sh = l >> 5;          // staging: this lane's accumulator row / half
+  const int c4 = l % W4, rsub = l / W4;          // read-back: float4 column and row inside a pass
+  const int ncol = n0 + wn0 + c4 * 4;            // first of this lane's 4 output columns
+  const bool cols_full = ncol + 3 < g.N;
+  // fast path: whole wave on aligned, in-range 4-column groups (always true off the N edge)
+  const bool fast = g.c_vec && __all(cols_full ? 1 : 0);
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias_mode == 1) {
+    const bf16* bp = reinterpret_cast<const bf16*>(g.bias);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = (float)bp[min(ncol + e, g.N - 1)];
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    // ---- stage fragment row block i
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cw = (j * 8 + 2 * q + sh) ^ (srow & (W4 - 1));
+        *reinterpret_cast<float4*>(buf + (srow * W4 + cw) * 4) =
+            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+      }
+    const int mbase = m0 + wm0 + i * 32 + rsub;
+    if (fast) {
+      // residual / accumulate rows of ALL passes requested up front (clamped row, discarded later)
+      bf16x4 rv[NPASS], cv[NPASS];
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const long mc = min(mbase + p * RPI, g.M - 1);
+        if (Rp) rv[p] = *reinterpret_cast<const bf16x4*>(Rp + mc * g.ldr + ncol);
+        if (g.accumulate) cv[p] = *reinterpret_cast<const bf16x4*>(C + mc * g.ldc + ncol);
+      }
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int row = p * RPI + rsub, m = mbase + p * RPI;
+        const float4 t = *reinterpret_cast<const float4*>(buf + (row * W4 + (c4 ^ (row & (W4 - 1)))) * 4);
+        float v[4] = {alpha * t.x, alpha * t.y, alpha * t.z, alpha * t.w};
+        if (g.bias_mode == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        } else if (g.bias_mode == 2) {
+          const float bm = (float)reinterpret_cast<const bf16*>(g.bias)[min(m, g.M - 1)];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bm;
+        }
+        if (g.act) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], g.act);
+        }
+        if (Rp) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rv[p][e];
+        }
+        if (g.accumulate) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)cv[p][e];
+        }
+        if (m < g.M) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+          *reinterpret_cast<bf16x4*>(C + (long)m * g.ldc + ncol) = o;
+        }
+      }
+    } else {
+      // N edge / unaligned C: same order of operations, element by element
+#pragma unroll 1
+      for (int p = 0; p < NPASS; ++p) {
+        const int row = p * RPI + rsub, m = mbase + p * RPI;
+        const float4 t = *reinterpret_cast<const float4*>(buf + (row * W4 + (c4 ^ (row & (W4 - 1)))) * 4);
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+        if (m >= g.M) continue;
+        float bm = 0.f;
+        if (g.bias_mode == 2) bm = (float)reinterpret_cast<const bf16*>(g.bias)[m];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = ncol + e;
+          if (n >= g.N) continue;
+          float x = alpha * tv[e];
+          if (g.bias_mode == 1) x += bv[e];
+          else if (g.bias_mode == 2) x += bm;
+          if (g.act) x = apply_act(x, g.act);
+          if (Rp) x += (float)Rp[(long)m * g.ldr + n];
+          bf16* cp = C + (long)m * g.ldc + n;
+          if (g.accumulate) x += (float)*cp;
+          *cp = (bf16)x;
+        }
+      }
+    }
+  }
+}
+
+// The compiler sometimes loses the wave-uniformity of a tile base pointer (then every
+// buffer_load ... lds becomes a 12-instruction waterfall loop over the descriptor): pin it.
+template <typename T>
+MK_DEV const T* uniform_ptr(const T* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<const T*>(((uint64_t)hi << 32) | lo);
+}
+
+}  // namespace mkg

@@ -376,7 +376,9 @@ class LMHeadLossFn(torch.autograd.Function):
         if dl is None:
             return None, None, None, None, None
         dlv = dl[:, :V]
-        dy = ops.linear_dx(dlv, lm_w)
+        # the pad columns [V, ldv) of dl are zero (ce_bwd writes the whole pitch, `ext` is
+        # zero-filled): the K = V reduction of dx runs on the tile kernels over the padded width
+        dy = ops.linear_dx(dlv, lm_w, dy_pad_zero=True)
         dlm = ops.linear_dw(dlv, y) if need[2] else None
         dh, dnw = ops.rmsnorm_bwd(dy, h2, norm_w, rstd)
         return dh.view(B, S, D), (dnw if need[1] else None), dlm, None, None

@@ -19,7 +19,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libmacaw_hip.so"
 
 MK_F32, MK_BF16, MK_F16, MK_FP8 = 0, 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _ERR = {-1: "MK_ERR_BAD_ARG", -2: "MK_ERR_UNSUPPORTED", -3: "MK_ERR_LAUNCH"}
 
@@ -43,6 +43,7 @@ class GemmDesc(C.Structure):
         ("dtype", C.c_int32),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("scale_a", C.c_void_p), ("scale_b", C.c_void_p),
+        ("flags", C.c_int32),
     ]
 
 
@@ -52,6 +53,7 @@ _vp, _i32, _i64, _f32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_u
 SIGNATURES = {
     "mk_abi_version": [],
     "mk_gemm": [C.POINTER(GemmDesc), _vp],
+    "mk_gemm_set_cfg": [_i32],
     "mk_prof_begin": [],
     "mk_prof_end": [_vp, _vp, _vp],
     "mk_prof_report": [C.c_char_p],

@@ -63,8 +63,10 @@ def _workspace(device):
 
 def gemm_raw(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_red=False, b_red=False, R=None, ldr=0,
              bias=None, bias_mode=0, act=0, accumulate=False, alpha=1.0, nb1=1, nb2=1,
-             sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), a_off=0, b_off=0, c_off=0, r_off=0):
-    """Direct struct fill. *_off are element offsets added to the base pointers."""
+             sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), a_off=0, b_off=0, c_off=0, r_off=0,
+             flags=0):
+    """Direct struct fill. *_off are element offsets added to the base pointers.
+    flags: MK_GEMM_A_KPAD_ZERO (1) / MK_GEMM_B_KPAD_ZERO (2), see include/macaw_hip.h."""
     lib = _L.load()
     es = A.element_size()
     d = GemmDesc()
@@ -86,6 +88,7 @@ def gemm_raw(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_red=False, b_red=False, R=No
     d.act = act
     d.accumulate = int(accumulate)
     d.dtype = dt(A)
+    d.flags = flags
     ws = _workspace(A.device)
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
     if B.dtype != A.dtype or Cc.dtype != A.dtype:
@@ -146,15 +149,19 @@ def linear_fwd(x, W, bias=None, act=0, residual=None, out=None, alpha=1.0):
     return out
 
 
-def linear_dx(dy, W, out=None, accumulate=False, residual=None):
-    """dx[M,K] = dy[M,N] @ W[N,K]  (W consumed red-major: no transpose pass)"""
+def linear_dx(dy, W, out=None, accumulate=False, residual=None, dy_pad_zero=False):
+    """dx[M,K] = dy[M,N] @ W[N,K]  (W consumed red-major: no transpose pass).
+    dy_pad_zero: dy is a column view of a pitched buffer whose columns [N, pad64(N)) are zero
+    (d(logits) for V = 32007): the reduction may then run over the padded width on the MFMA tile
+    kernels instead of the generic edge kernel."""
     M, N = dy.shape
     K = W.shape[1]
     if out is None:
         out = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
     gemm_raw(dy, W, out, M, K, N, _rowmajor(dy), _rowmajor(W), _rowmajor(out), b_red=True,
              accumulate=accumulate, R=residual,
-             ldr=_rowmajor(residual) if residual is not None else 0)
+             ldr=_rowmajor(residual) if residual is not None else 0,
+             flags=1 if dy_pad_zero else 0)
     return out
 
 

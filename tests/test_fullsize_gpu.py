@@ -197,6 +197,26 @@ def test_fast_gemm_matches_exact_fp32_mfma_at_full_size(dev, M, N, K):
     assert torch.equal(y2, (y.float() * 2).to(torch.bfloat16))
 
 
+def test_production_gemm_vs_torch_fp32_at_full_size(dev):
+    """one full-size LLaMA shape per layout against torch.matmul in fp32 on the GPU (an
+    implementation independent of this library: rocBLAS), whole output, default dispatch (the
+    256x256 v7 kernel with its sub-tile tail at 288 / 1548 tiles)."""
+    M, D, FF = 4608, 4096, 11008
+    g = torch.Generator(device="cpu").manual_seed(77)
+    x = _bf(torch.randn(M, D, generator=g)).to(dev)
+    W = _bf(torch.randn(FF, D, generator=g) * 0.02).to(dev)
+    dy = _bf(torch.randn(M, FF, generator=g)).to(dev)
+
+    def chk(got, ref, what):
+        err = (got.float() - ref).abs().max().item()
+        lim = 2 ** -8 * ref.abs().max().item() + 2e-3     # one bf16 rounding of the fp32 result
+        assert err <= lim, f"{what}: {err} > {lim}"
+
+    chk(ops.linear_fwd(x, W), x.float() @ W.float().t(), "fwd 4608x11008x4096")
+    chk(ops.linear_dx(dy, W), dy.float() @ W.float(), "dx 4608x4096x11008")
+    chk(ops.linear_dw(dy, x), dy.float().t() @ x.float(), "dW 11008x4096x4608")
+
+
 def test_fused_attention_matches_gemm_softmax_path_at_seq_2048(dev):
     """BASELINE cfg 4 sequence length: fused kernels vs the batched GEMM + softmax formulation."""
     g = torch.Generator().manual_seed(5)

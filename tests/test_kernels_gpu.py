@@ -54,6 +54,83 @@ def test_gemm_layouts(dev, dtype, a_red, b_red, M, N, K):
     _close(C, ref, dtype, scale=math.sqrt(K), what=f"gemm {M}x{N}x{K} {a_red}{b_red}")
 
 
+@pytest.mark.parametrize("a_red,b_red", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(300, 520, 128), (513, 1000, 192), (1031, 776, 320), (256, 256, 64 * 7),
+                                   (2176, 1096, 1024)])
+def test_gemm_v7_256_tile_kernel(dev, a_red, b_red, M, N, K):
+    """the 256x256 quadrant-phase kernel (csrc/gemm_v7.hip) forced on ragged / short-K problems:
+    whole tiles, the 128x128 sub-tile tail, nk = 2, 3, 5, 7 (prologue / penultimate / last tile
+    paths), every operand layout -- against torch fp32 matmul on the same bf16 inputs, and within
+    one bf16 ulp of the 128x128 kernel (whose K-split tail may re-associate the fp32 sum)."""
+    from macaw_llm_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    A = _rand((K, M) if a_red else (M, K), torch.bfloat16, g)
+    B = _rand((K, N) if b_red else (N, K), torch.bfloat16, g, 0.1)
+    ref = (A.float().t() if a_red else A.float()) @ (B.float() if b_red else B.float().t())
+    Ad, Bd = A.to(dev), B.to(dev)
+    ldc = (N + 7) // 8 * 8
+    outs = {}
+    try:
+        for cfg in (11, 5):
+            lib.mk_gemm_set_cfg(cfg)
+            C = torch.full((M, ldc), float("nan"), dtype=torch.bfloat16, device=dev)
+            ops.gemm_raw(Ad, Bd, C, M, N, K, Ad.stride(0), Bd.stride(0), ldc, a_red=a_red, b_red=b_red)
+            outs[cfg] = C
+    finally:
+        lib.mk_gemm_set_cfg(-1)
+    _close(outs[11][:, :N], ref, torch.bfloat16, scale=0.1 * math.sqrt(K), what=f"v7 {M}x{N}x{K} {a_red}{b_red}")
+    assert torch.isnan(outs[11][:, N:].float()).all()      # pad columns of C untouched
+    # agreement with the 128x128 kernel up to one bf16 ulp of the result (its K-split tail may
+    # re-associate the fp32 sum)
+    d = (outs[11][:, :N].float() - outs[5][:, :N].float()).abs().max().item()
+    assert d <= 2 ** -7 * ref.abs().max().item() + 1e-6
+
+
+def test_gemm_odd_rows_reduction_major_last_element(dev):
+    """regression: the hardware buffer range check is per DWORD -- with an odd row count the last
+    valid element of the last k-row of a reduction-major operand shares its dword with the first
+    out-of-range one and used to load as zero (the k = K-1 product of output row M-1 was lost;
+    lm_head dW, V = 32007).  Make that single product dominate the result."""
+    M, N, K = 775, 320, 256
+    ldm = 776
+    A = torch.zeros((K, ldm), dtype=torch.bfloat16)
+    A[K - 1, M - 1] = 64.0
+    B = torch.zeros((K, N), dtype=torch.bfloat16)
+    B[K - 1] = torch.arange(N, dtype=torch.float32).to(torch.bfloat16)
+    from macaw_llm_amd import lib as L
+    lib = L.load()
+    try:
+        for cfg in (5, 11):
+            lib.mk_gemm_set_cfg(cfg)
+            C = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+            ops.gemm_raw(A.to(dev), B.to(dev), C, M, N, K, ldm, N, N, a_red=True, b_red=True)
+            want = 64.0 * B[K - 1].float()
+            assert torch.equal(C[M - 1].float().cpu(), want.to(torch.bfloat16).float()), cfg
+            assert not C[: M - 1].any()
+    finally:
+        lib.mk_gemm_set_cfg(-1)
+
+
+@pytest.mark.parametrize("K", [1031, 2007])
+def test_gemm_k_tail_with_zero_padded_pitch(dev, K):
+    """MK_GEMM_A_KPAD_ZERO: a K that is not a multiple of 64 on the MFMA tile kernels when the
+    K-major operand is a pitched buffer with zero pad columns (d(logits) [tokens, 32064] x W for
+    V = 32007) -- same result as the generic kernel / fp32 matmul, incl. odd K."""
+    M, N = 520, 392
+    g = torch.Generator().manual_seed(K)
+    kp = (K + 63) // 64 * 64
+    dy = torch.zeros((M, kp), dtype=torch.bfloat16)
+    dy[:, :K] = _rand((M, K), torch.bfloat16, g)
+    W = _rand((K, N), torch.bfloat16, g, 0.1)
+    ref = dy[:, :K].float() @ W.float()
+    dyd, Wd = dy.to(dev), W.to(dev)
+    got = ops.linear_dx(dyd[:, :K], Wd, dy_pad_zero=True)
+    _close(got, ref, torch.bfloat16, scale=0.1 * math.sqrt(K), what="k-tail padded")
+    plain = ops.linear_dx(dyd[:, :K], Wd)          # generic edge kernel
+    assert (got.float() - plain.float()).abs().max().item() <= 2 ** -7 * ref.abs().max().item() + 1e-6
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_epilogues(dev, dtype):
     g = torch.Generator().manual_seed(5)
