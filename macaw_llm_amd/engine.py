@@ -390,49 +390,25 @@ class LMHeadLossFn(torch.autograd.Function):
 ACT_CODE = {"gelu": 1, "quick_gelu": 2}
 
 
-_FROZEN_QKV = {}
-
-
-def _frozen_qkv(wq, bq, wk, bk, wv, bv):
-    """[3E, E] weight and [3E] bias of a FROZEN encoder layer's q / k / v projections, built once
-    (the reference always freezes the towers, run_clm_llms.py:390-393): one GEMM with N = 3E
-    instead of three with N = E (CLIP 8224 x 1024 x 1024: 405 -> ~600 TFLOP/s per launch)."""
-    key = tuple((t.data_ptr(), t._version) for t in (wq, wk, wv) + tuple(b for b in (bq, bk, bv) if b is not None))
-    ent = _FROZEN_QKV.get(key)
-    if ent is None:
-        if len(_FROZEN_QKV) > 512:
-            _FROZEN_QKV.clear()
-        E = wq.shape[0]
-        W = torch.empty((3 * E, wq.shape[1]), dtype=wq.dtype, device=wq.device)
-        b = torch.empty((3 * E,), dtype=wq.dtype, device=wq.device)
-        ops.fill_(b, 0.0)
-        for i, (w_, b_) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
-            wc = w_ if w_.is_contiguous() else w_.contiguous()
-            ops.copy2d(wc, W, E, wc.shape[1], wc.shape[1], wc.shape[1], dst_off=i * E * wc.shape[1])
-            if b_ is not None:
-                ops.copy2d(b_.view(1, E), b.view(1, 3 * E), 1, E, E, 3 * E, dst_off=i * E)
-        ent = _FROZEN_QKV[key] = (W, b)
-    return ent
-
-
 class EncoderLayerFn(torch.autograd.Function):
-    """x + attn(LN1(x)) ; h + fc2(act(fc1(LN2(h)))).  k_proj bias may be None (Whisper)."""
+    """x + attn(LN1(x)) ; h + fc2(act(fc1(LN2(h)))).  k_proj bias may be None (Whisper).
+    w3 / b3: the [3E, E] / [3E] views ALIASING wq|wk|wv and their biases when the module keeps
+    them back to back (modeling.fused_encoder_qkv), else None."""
 
     @staticmethod
     def forward(ctx, x, n_heads, eps, act, ln1w, ln1b, wq, bq, wk, bk, wv, bv, wo, bo, ln2w, ln2b,
-                w1, b1, w2, b2):
+                w1, b1, w2, b2, w3=None, b3=None):
         B, T, E = x.shape
         M, H, hd = B * T, n_heads, E // n_heads
         x2 = _c2(x, M, E)
         y1, mean1, rstd1 = ops.layernorm_fwd(x2, ln1w, ln1b, eps)
         grad_mode = any(ctx.needs_input_grad)
-        if grad_mode:
+        if grad_mode or w3 is None:
             q = ops.linear_fwd(y1, wq, bias=bq)
             k = ops.linear_fwd(y1, wk, bias=bk)
             v = ops.linear_fwd(y1, wv, bias=bv)
             ldq = E
-        else:   # frozen tower / inference: one q|k|v GEMM
-            w3, b3 = _frozen_qkv(wq, bq, wk, bk, wv, bv)
+        else:   # frozen tower / inference: one q|k|v GEMM on the module's fused storage
             qkv = ops.linear_fwd(y1, w3, bias=b3)
             q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
             ldq = 3 * E
@@ -492,7 +468,7 @@ class EncoderLayerFn(torch.autograd.Function):
         dwv, dbv = ops.linear_dw(dv, y1), ops.colsum(dv)
         dx, dln1w, dln1b = ops.layernorm_bwd(dy1, x2, ln1w, mean1, rstd1, dres=dh1)
         return (dx.view(B, T, E), None, None, None, dln1w, dln1b, dwq, dbq, dwk, dbk, dwv, dbv, dwo,
-                dbo, dln2w, dln2b, dw1, db1, dw2, db2)
+                dbo, dln2w, dln2b, dw1, db1, dw2, db2, None, None)
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -34,7 +34,7 @@ def build_model(cfg: dict, dtype=torch.bfloat16, device="cuda", seed=1234, freez
     with _default_dtype(dtype), torch.device(device):
         model = M.MM_LLMs(make_config(cfg))
     model = model.to(device=device, dtype=dtype)
-    if fuse:
+    if fuse:   # (a model built without this fuses lazily at its first forward: modeling.AUTO_FUSE)
         for layer in model.llm.model.layers:
             layer.fuse_projections()
     if freeze_encoders:

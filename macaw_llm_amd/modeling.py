@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 from typing import List, Optional, Tuple, Union
 
 import numpy as np
@@ -35,6 +36,91 @@ def _dev_check(t: torch.Tensor):
     if not t.is_cuda:
         raise MacawHipError("macaw_llm_amd runs on the HIP device only (model and inputs must be on "
                             "'cuda'); there is no CPU path")
+
+
+def _dtype_check(dtype):
+    """The MFMA kernels are bf16 (fp32 = parity mode).  The reference's scripts default to fp16
+    (train.sh `--fp16 True`, llm_trainer.py:411-412 `.to(torch.float16)`): fail with the remedy
+    instead of MK_ERR_UNSUPPORTED from the first Linear."""
+    if dtype not in (torch.bfloat16, torch.float32):
+        raise MacawHipError(f"macaw_llm_amd: model parameters are {dtype}; the gfx950 kernels implement "
+                            "bfloat16 (and float32 for parity runs).  Use `--bf16 True` instead of `--fp16 "
+                            "True` (configs/deepspeed_config_bf16.json) / `model.to(torch.bfloat16)`; "
+                            "fp16 INPUT tensors are fine (they are cast to the parameter dtype).")
+
+
+# Parameters that feed one GEMM (q|k|v, gate|up) are re-homed back to back in ONE buffer the first
+# time a layer runs on the device (and again after .to() / .cuda() / any re-materialisation gave
+# them separate storage), so a model built the reference's way -- MM_LLMs(config), .to(), Trainer --
+# runs the same fused GEMMs as factory.build_model.  MACAW_NO_AUTO_FUSE=1 disables it.
+AUTO_FUSE = os.environ.get("MACAW_NO_AUTO_FUSE") is None
+
+
+def _rows_view(ts):
+    """tensor [sum rows, ...] aliasing `ts` if they lie back to back in one storage, else None"""
+    t0 = ts[0]
+    ptr, es = t0.data_ptr(), t0.element_size()
+    inner = t0[0].numel() if t0.dim() > 1 else 1
+    rows = 0
+    for t in ts:
+        if (not t.is_contiguous() or t.data_ptr() != ptr + rows * inner * es or t.dtype != t0.dtype
+                or t.shape[1:] != t0.shape[1:] or t.device != t0.device):
+            return None
+        rows += t.shape[0]
+    try:
+        return t0.data.as_strided((rows,) + tuple(t0.shape[1:]), t0.stride())
+    except RuntimeError:   # not inside one storage
+        return None
+
+
+@torch.no_grad()
+def _rehome_rows(ts):
+    """concatenate along dim 0 into one new buffer and make every tensor a view of it"""
+    fused = torch.cat([t.data for t in ts], dim=0).contiguous()
+    off = 0
+    for t in ts:
+        t.data = fused[off:off + t.shape[0]]
+        off += t.shape[0]
+    return fused
+
+
+def fused_encoder_qkv(attn):
+    """([3E, E] weight, [3E] bias) aliasing the q/k/v projections of a HF CLIPAttention /
+    WhisperAttention module (one GEMM with N = 3E instead of three).  The parameters themselves
+    are re-homed (same state-dict keys), so there is no copy that could go stale when the towers
+    are trained or reloaded; a missing k bias (Whisper) is a zero slot of the bias buffer.
+    Returns (None, None) when fusing is off or the module is not on the device."""
+    q, k, v = attn.q_proj, attn.k_proj, attn.v_proj
+    ws = (q.weight, k.weight, v.weight)
+    E = q.weight.shape[0]
+    W3 = _rows_view(ws)
+    b3 = getattr(attn, "_macaw_b3", None)
+    es = q.weight.element_size()
+
+    def bias_ok():
+        if b3 is None or b3.dtype != q.weight.dtype or b3.device != q.weight.device or b3.numel() != 3 * E:
+            return False
+        if q.bias is None or v.bias is None:
+            return False
+        ok = q.bias.data_ptr() == b3.data_ptr() and v.bias.data_ptr() == b3.data_ptr() + 2 * E * es
+        return ok and (k.bias is None or k.bias.data_ptr() == b3.data_ptr() + E * es)
+
+    if W3 is not None and bias_ok():
+        return W3, b3
+    if not (AUTO_FUSE and q.weight.is_cuda) or q.bias is None or v.bias is None:
+        return None, None
+    with torch.no_grad():
+        if W3 is None:
+            _rehome_rows(ws)
+            W3 = _rows_view(ws)
+        b3 = torch.empty(3 * E, dtype=q.weight.dtype, device=q.weight.device)
+        ops.fill_(b3, 0.0)
+        for i, lin in enumerate((q, k, v)):
+            if lin.bias is not None:
+                b3[i * E:(i + 1) * E].copy_(lin.bias.data)
+                lin.bias.data = b3[i * E:(i + 1) * E]
+        attn._macaw_b3 = b3
+    return W3, b3
 
 
 # ---------------------------------------------------------------- LLaMA -----
@@ -123,28 +209,27 @@ class LlamaDecoderLayer(nn.Module):
         a, m = self.self_attn, self.mlp
         for mods in ((a.q_proj, a.k_proj, a.v_proj), (m.gate_proj, m.up_proj)):
             ws = [x.weight for x in mods]
-            fused = torch.cat([w.data for w in ws], dim=0).contiguous()
-            off = 0
-            for w in ws:
-                w.data = fused[off:off + w.shape[0]]
-                off += w.shape[0]
+            if _rows_view(ws) is None:
+                _rehome_rows(ws)
         return self
 
     @staticmethod
     def _fused_view(ws):
         """[sum rows, D] tensor aliasing the parameters if they are laid out back to back"""
-        w0 = ws[0]
-        ptr, es = w0.data_ptr(), w0.element_size()
-        rows = 0
-        for w in ws:
-            if (not w.is_contiguous() or w.data_ptr() != ptr + rows * w0.shape[1] * es
-                    or w.dtype != w0.dtype or w.shape[1] != w0.shape[1]):
-                return None
-            rows += w.shape[0]
-        try:
-            return w0.data.as_strided((rows, w0.shape[1]), (w0.shape[1], 1))
-        except RuntimeError:   # not inside one storage
-            return None
+        return _rows_view(ws)
+
+    def fused_weights(self):
+        """(wqkv, wgu) views; fuses lazily on the device (AUTO_FUSE) so that the reference's own
+        construction path -- MM_LLMs(config) -> resize_token_embeddings -> .to(dtype / device),
+        run_clm_llms.py:478-497 -- gets the one-GEMM projections too."""
+        a, m = self.self_attn, self.mlp
+        qkv = (a.q_proj.weight, a.k_proj.weight, a.v_proj.weight)
+        gu = (m.gate_proj.weight, m.up_proj.weight)
+        wqkv, wgu = self._fused_view(qkv), self._fused_view(gu)
+        if (wqkv is None or wgu is None) and AUTO_FUSE and qkv[0].is_cuda:
+            self.fuse_projections()
+            wqkv, wgu = self._fused_view(qkv), self._fused_view(gu)
+        return wqkv, wgu
 
     def forward(self, hidden_states, kmask=None, pos=None, past_key_value=None, use_cache=False,
                 recompute=False):
@@ -153,8 +238,7 @@ class LlamaDecoderLayer(nn.Module):
         if past_key_value is not None or use_cache:
             raise NotImplementedError("KV-cache decode goes through LlamaForCausalLM.generate")
         a, m = self.self_attn, self.mlp
-        wqkv = self._fused_view((a.q_proj.weight, a.k_proj.weight, a.v_proj.weight))
-        wgu = self._fused_view((m.gate_proj.weight, m.up_proj.weight))
+        wqkv, wgu = self.fused_weights()
         cos, sin = a.rotary_emb.tables(hidden_states.shape[1], hidden_states.dtype,
                                        hidden_states.device)
         out = eng.LlamaLayerFn.apply(
@@ -394,9 +478,7 @@ class LlamaForCausalLM(LlamaPreTrainedModel):
                     lyr.input_layernorm.variance_epsilon, a.q_proj.weight, a.k_proj.weight,
                     a.v_proj.weight, a.o_proj.weight, m.gate_proj.weight, m.up_proj.weight,
                     m.down_proj.weight, lyr.input_layernorm.weight,
-                    lyr.post_attention_layernorm.weight,
-                    lyr._fused_view((a.q_proj.weight, a.k_proj.weight, a.v_proj.weight)),
-                    lyr._fused_view((m.gate_proj.weight, m.up_proj.weight)))
+                    lyr.post_attention_layernorm.weight, *lyr.fused_weights())
             return x2
 
         h = run(eng._c2(inputs_embeds, B * S0, D), S0, 0)                 # prefill
@@ -564,6 +646,7 @@ class MM_LLMs(PreTrainedModel):
 
     # ------------------------------------------------------------ forward ---
     def forward(self, inputs=None):
+        _dtype_check(self._param_dtype())
         text_embeddings, attention_mask, labels = self.prepare_inputs_for_generation(inputs)
         if "inference" in inputs and inputs["inference"] is True:
             return self.llm.generate(inputs_embeds=text_embeddings, max_new_tokens=128,
@@ -645,7 +728,7 @@ class MM_LLMs(PreTrainedModel):
                 lyr.layer_norm1.bias, a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias,
                 a.v_proj.weight, a.v_proj.bias, a.out_proj.weight, a.out_proj.bias,
                 lyr.layer_norm2.weight, lyr.layer_norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
-                m.fc2.bias)
+                m.fc2.bias, *fused_encoder_qkv(a))
         return eng.DropClsProjectFn.apply(h, clip.visual_projection.weight)
 
     def encode_image(self, images):
@@ -672,7 +755,7 @@ class MM_LLMs(PreTrainedModel):
                 lyr.self_attn_layer_norm.bias, a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, None,
                 a.v_proj.weight, a.v_proj.bias, a.out_proj.weight, a.out_proj.bias,
                 lyr.final_layer_norm.weight, lyr.final_layer_norm.bias, lyr.fc1.weight, lyr.fc1.bias,
-                lyr.fc2.weight, lyr.fc2.bias)
+                lyr.fc2.weight, lyr.fc2.bias, *fused_encoder_qkv(a))
         return eng.LayerNormFn.apply(h, enc.layer_norm.weight, enc.layer_norm.bias, 1e-5)
 
     def encode_video_long(self, videos):

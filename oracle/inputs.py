@@ -39,3 +39,39 @@ def make_inputs(cfg: dict, batch: int, text_len: int, modalities=("images", "aud
         inputs[f"{name}_starts"] = torch.full((batch,), s, dtype=torch.int32)
         inputs[f"{name}_ends"] = torch.full((batch,), e, dtype=torch.int32)
     return inputs
+
+
+# ---- seeded recipe of the real-dimension single-layer fixture (oracle/make_golden.py
+# make_real7b_layer and tests/test_fullsize_gpu.py regenerate identical tensors from it)
+def _bf16_exact(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def real7b_layer_weights(seed: int, head_rows: int = 512):
+    """weights of one LLaMA-7B decoder layer (reference parameter names under 'layer.'), the
+    final norm and `head_rows` rows of lm_head; N(0, 0.02) like HF init, norm weights around 1,
+    every value exactly representable in bf16."""
+    g = torch.Generator().manual_seed(seed)
+    D, FF = 4096, 11008
+    shapes = [("layer.self_attn.q_proj.weight", (D, D)), ("layer.self_attn.k_proj.weight", (D, D)),
+              ("layer.self_attn.v_proj.weight", (D, D)), ("layer.self_attn.o_proj.weight", (D, D)),
+              ("layer.mlp.gate_proj.weight", (FF, D)), ("layer.mlp.down_proj.weight", (D, FF)),
+              ("layer.mlp.up_proj.weight", (FF, D))]
+    w = {n: _bf16_exact(torch.randn(s, generator=g) * 0.02) for n, s in shapes}
+    for n in ("layer.input_layernorm.weight", "layer.post_attention_layernorm.weight", "norm.weight"):
+        w[n] = _bf16_exact(1.0 + 0.1 * torch.randn(D, generator=g))
+    w["lm_head.weight"] = _bf16_exact(torch.randn(head_rows, D, generator=g) * 0.02)
+    return w
+
+
+def real7b_layer_inputs(seed: int, B: int, S: int):
+    g = torch.Generator().manual_seed(seed + 1)
+    x = _bf16_exact(torch.randn(B, S, 4096, generator=g))
+    am = torch.ones(B, S, dtype=torch.long)
+    am[-1, S - 5:] = 0                      # right padding on the last sample
+    return x, am
+
+
+def real7b_layer_cotangent(seed: int, B: int, S: int, head_rows: int):
+    g = torch.Generator().manual_seed(seed + 2)
+    return _bf16_exact(torch.randn(B, S, head_rows, generator=g) / 64)

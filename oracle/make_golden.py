@@ -67,12 +67,56 @@ def make(name, cfg_name, batch, text_len, modalities, pad_tail, seed=1234, with_
           f"{os.path.getsize(path)/1e6:.2f} MB, {len(grads)} grads", file=sys.stderr)
 
 
+# ---- real-dimension fixture: ONE LLaMA-7B decoder layer + final norm + a slice of lm_head, run by
+# the reference's own classes.  The 203 M weights are not stored: both sides regenerate them from
+# the seeded recipe in oracle/inputs.py (real7b_layer_weights), bf16-exact values.
+def make_real7b_layer(name="real7b_layer", seed=4242, B=2, S=24, head_rows=512):
+    mod = ref_loader.load_reference_modeling()
+    from transformers import LlamaConfig
+    lcfg = LlamaConfig(**configs.get("real_7b")["llama"])
+    lcfg._attn_implementation = "eager"
+    layer = mod.LlamaDecoderLayer(lcfg).eval()
+    norm = mod.LlamaRMSNorm(lcfg.hidden_size, eps=lcfg.rms_norm_eps)
+    w = oin.real7b_layer_weights(seed, head_rows)
+    with torch.no_grad():
+        for n, p in layer.named_parameters():
+            p.copy_(w["layer." + n])
+        norm.weight.copy_(w["norm.weight"])
+    head = w["lm_head.weight"]
+    x, am = oin.real7b_layer_inputs(seed, B, S)
+    x = x.clone().requires_grad_(True)
+    # the mask / position ids exactly as LlamaModel.forward builds them (modeling.py:434-450)
+    mask = restate.decoder_mask(am, B, S, torch.float32, x.device)
+    pos = torch.arange(S).unsqueeze(0)
+    h = layer(x, attention_mask=mask, position_ids=pos)[0]
+    logits = torch.nn.functional.linear(norm(h), head)
+    # a scalar functional of the logits drives the backward (fixed cotangent)
+    cot = oin.real7b_layer_cotangent(seed, B, S, head_rows)
+    (logits * cot).sum().backward()
+    named = dict(layer.named_parameters())
+    fx = dict(seed=seed, B=B, S=S, head_rows=head_rows, layer_out=h.detach(), logits=logits.detach(),
+              dx=x.grad.detach(),
+              dq_rows=named["self_attn.q_proj.weight"].grad[:8].clone(),
+              ddown_rows=named["mlp.down_proj.weight"].grad[:8].clone(),
+              dgate_rows=named["mlp.gate_proj.weight"].grad[5000:5008].clone(),
+              dnorm1=named["input_layernorm.weight"].grad.clone(),
+              grad_norms={n: p.grad.norm().item() for n, p in named.items()})
+    path = os.path.join(GOLDEN_DIR, name + ".pt")
+    torch.save(fx, path)
+    print(f"{name}: |out| {h.abs().max().item():.3f} |logits| {logits.abs().max().item():.3f} "
+          f"{os.path.getsize(path)/1e6:.2f} MB", file=sys.stderr)
+
+
 def main():
     if not ref_loader.reference_available():
         raise SystemExit("needs /root/reference")
+    if "--real7b-only" in sys.argv:
+        make_real7b_layer()
+        return
     make("micro_all", "micro", batch=2, text_len=12, modalities=("images", "audios", "videos"),
          pad_tail=3, with_generate=True)
     make("micro_image", "micro", batch=1, text_len=9, modalities=("images",), pad_tail=0)
+    make_real7b_layer()
 
 
 if __name__ == "__main__":

@@ -332,10 +332,12 @@ def prepare_inputs(sd: SD, inputs: dict, cfg: dict, hoist: bool = True):
 
     am = None
     if "attention_mask" in inputs and inputs["attention_mask"] is not None:
-        am = torch.cat([torch.ones(B, ignore, dtype=inputs["attention_mask"].dtype), inputs["attention_mask"]], dim=1)
+        am = torch.cat([torch.ones(B, ignore, dtype=inputs["attention_mask"].dtype,
+                                   device=inputs["attention_mask"].device), inputs["attention_mask"]], dim=1)
     lab = None
     if inputs.get("labels") is not None:
-        lab = torch.cat([torch.full((B, ignore), -100, dtype=inputs["labels"].dtype), inputs["labels"]], dim=1)
+        lab = torch.cat([torch.full((B, ignore), -100, dtype=inputs["labels"].dtype,
+                                    device=inputs["labels"].device), inputs["labels"]], dim=1)
     return text, am, lab, aux
 
 

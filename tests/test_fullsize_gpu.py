@@ -289,17 +289,110 @@ def test_real_dimension_encoders_and_prefix_vs_oracle(dev):
     assert abs(out.loss.item() - ref["loss"].item()) <= 2e-2 * max(1.0, abs(ref["loss"].item()))
 
 
-def test_full_llama7b_size_independent_properties(dev, monkeypatch):
-    """BASELINE cfg 3 at FULL size (32-layer LLaMA-7B + CLIP-L/14 + Whisper-base, vocab 32,007,
-    image + audio + 128 tokens) where no CPU oracle can run: size-independent properties of the
-    whole model on the same random weights and inputs --
-      * the production path (fused q|k|v / gate|up GEMMs, fused attention) against the
-        formulation that was validated line by line against the reference on the micro model
-        (separate projections, batched-GEMM + softmax attention): logits within the bf16 bound,
-      * activation checkpointing: loss and every gradient bit-identical to the plain step,
-      * the extended attention mask / labels (integer work) bit-exact between the two runs and
-        consistent with the prefix layout (S = 128 + 2 * (2 + 6) for image + audio).
-    """
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_real7b_layer_against_reference_golden(dev, dtype):
+    """REAL-DIMENSION parity against the reference ITSELF (not the restatement):
+    tests/golden/real7b_layer.pt holds one LLaMA-7B decoder layer + final RMSNorm + 512 lm_head
+    rows computed by /root/reference's LlamaDecoderLayer / LlamaRMSNorm in fp32
+    (oracle/make_golden.py), weights regenerated here from the same seeded recipe.
+      fp32 engine : north_star's bound -- logits within 1e-3 of the reference (measured ~1e-5)
+      bf16 engine : activations stored in bf16 (2^-8): <= 2.5 % of the largest magnitude
+    and the backward (d input, rows of dW for q / gate / down, d RMSNorm weight)."""
+    import os
+    from golden_util import GOLDEN_DIR
+    from transformers import LlamaConfig
+    from macaw_llm_amd import modeling as M
+    from macaw_llm_amd.factory import baseline_config
+    from oracle import inputs as oin
+    fx = torch.load(os.path.join(GOLDEN_DIR, "real7b_layer.pt"), weights_only=False)
+    B, S, R = fx["B"], fx["S"], fx["head_rows"]
+    w = oin.real7b_layer_weights(fx["seed"], R)
+    x, am = oin.real7b_layer_inputs(fx["seed"], B, S)
+    lcfg = LlamaConfig(**baseline_config("real_7b")["llama"])
+    layer = M.LlamaDecoderLayer(lcfg)
+    layer.load_state_dict({k[len("layer."):]: v for k, v in w.items() if k.startswith("layer.")}, strict=False)
+    layer = layer.to(dev).to(dtype)
+    norm_w = torch.nn.Parameter(w["norm.weight"].to(dev).to(dtype))
+    head = torch.nn.Parameter(w["lm_head.weight"].to(dev).to(dtype))
+    xg = x.to(dev).to(dtype).requires_grad_(True)
+    pos = torch.arange(S, dtype=torch.int32, device=dev).repeat(B)
+    h = layer(xg, kmask=am.to(torch.int32).to(dev), pos=pos)[0]
+    logits = eng.LinearFn.apply(eng.RMSNormFn.apply(h, norm_w, 1e-6), head, None, 0)
+    cot = oin.real7b_layer_cotangent(fx["seed"], B, S, R).to(dev).to(dtype)
+    (logits * cot).sum().backward()
+    named = dict(layer.named_parameters())
+
+    def rel(got, want):
+        return (got.float().cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
+
+    err_out = (h.float().cpu() - fx["layer_out"]).abs().max().item()
+    err_log = (logits.float().cpu() - fx["logits"]).abs().max().item()
+    scale_out, scale_log = fx["layer_out"].abs().max().item(), fx["logits"].abs().max().item()
+    g = dict(dx=rel(xg.grad, fx["dx"]),
+             dq=rel(named["self_attn.q_proj.weight"].grad[:8], fx["dq_rows"]),
+             ddown=rel(named["mlp.down_proj.weight"].grad[:8], fx["ddown_rows"]),
+             dgate=rel(named["mlp.gate_proj.weight"].grad[5000:5008], fx["dgate_rows"]),
+             dnorm1=rel(named["input_layernorm.weight"].grad, fx["dnorm1"]))
+    print(f"real7b layer {dtype}: |d out| {err_out:.3e} of {scale_out:.2f}, |d logits| {err_log:.3e} of "
+          f"{scale_log:.2f}, grads (max err / max) {g}")
+    if dtype == torch.float32:
+        assert err_log < 1e-3 and err_out < 1e-3
+        assert all(v < 2e-4 for v in g.values()), g
+    else:
+        assert err_log <= 2.5e-2 * scale_log and err_out <= 2.5e-2 * scale_out
+        assert all(v < 4e-2 for v in g.values()), g
+
+
+def _gpu_oracle_state(model):
+    """fp32 copy of the hot-path state on the GPU for oracle.restate (torch ops = rocBLAS / MIOpen:
+    an implementation independent of this library)"""
+    return restate.hot_path_state({k: v.detach().float() for k, v in model.state_dict().items()})
+
+
+def test_full_llama7b_against_fp32_oracle_on_gpu(dev):
+    """BASELINE cfg 3 at FULL depth and width (32-layer LLaMA-7B + CLIP-L/14 + Whisper-base, vocab
+    32,007, image + 30 s audio + 128 tokens, B = 2) against the ORACLE, not against ourselves:
+    oracle.restate.mm_forward runs in fp32 with plain torch ops on the GPU (27 GB of weights in a
+    288 GB part) -- the reference formulation pinned to the reference by tests/test_oracle.py -- and
+    once more in eager bf16, which is the yardstick SURVEY section 7 asks for ("the same reference
+    code run in bf16 on PyTorch-ROCm").  Asserted: integer outputs bit-exact; loss within 2e-2;
+    the HIP engine's logits error vs the fp32 oracle is no larger than 1.5 x the eager-bf16 error
+    (both printed; DESIGN.md section 2 quotes them)."""
+    from macaw_llm_amd.factory import baseline_config, build_model, synthetic_inputs
+    cfg = baseline_config("real_7b")
+    model = build_model(cfg, dtype=torch.bfloat16, device=dev, seed=11, fuse=True).eval()
+    inp = synthetic_inputs(cfg, 2, 128, modalities=("images", "audios"), seed=5, device=dev)
+    with torch.no_grad():
+        out = model(inputs=inp)
+        emb, am, lab = model.prepare_inputs_for_generation(inp)
+        sd32 = _gpu_oracle_state(model)
+        f32 = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}
+        ref = restate.mm_forward(sd32, f32, cfg)
+        ref_logits = ref["logits"].float()
+        sd16 = {k: v.to(torch.bfloat16) for k, v in sd32.items()}
+        b16 = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}
+        eager = restate.mm_forward(sd16, b16, cfg)
+    assert torch.equal(am, ref["attention_mask"]) and torch.equal(lab, ref["labels"])     # INT: bit exact
+    assert out.logits.shape == ref_logits.shape == (2, 144, 32007)
+
+    def rel(a):
+        d = (a.float() - ref_logits).abs()
+        return d.max().item() / ref_logits.abs().max().item(), d.mean().item() / ref_logits.abs().mean().item()
+
+    hip, eag = rel(out.logits), rel(eager["logits"])
+    emb_err = (emb.float() - ref["inputs_embeds"]).abs().max().item() / ref["inputs_embeds"].abs().max().item()
+    print(f"full 7B vs fp32 oracle (max/max, mean/mean): HIP bf16 {hip}, eager bf16 {eag}; "
+          f"inputs_embeds {emb_err:.3e}; loss HIP {out.loss.item():.5f} eager {eager['loss'].item():.5f} "
+          f"fp32 {ref['loss'].item():.5f}")
+    assert hip[0] <= 1.5 * eag[0] + 5e-3 and hip[1] <= 1.5 * eag[1] + 2e-3, (hip, eag)
+    assert abs(out.loss.item() - ref["loss"].item()) <= 2e-2 * max(1.0, abs(ref["loss"].item()))
+    assert emb_err <= 5e-2
+
+
+def test_full_llama7b_checkpointing_bit_identical_and_gradients_vs_oracle(dev):
+    """full-size training step: activation checkpointing reproduces loss and every gradient bit for
+    bit, and the gradients of the last decoder layer / lm_head agree with autograd through the
+    fp32 oracle on the GPU (relative L2 error of bf16 storage through 32 layers: <= 6 %)."""
     from macaw_llm_amd.factory import baseline_config, build_model, synthetic_inputs
     cfg = baseline_config("real_7b")
     model = build_model(cfg, dtype=torch.bfloat16, device=dev, seed=11, fuse=True).eval()
@@ -315,10 +408,6 @@ def test_full_llama7b_size_independent_properties(dev, monkeypatch):
         return out.loss.detach().clone(), out.logits.detach().clone(), g
 
     loss0, logits0, g0 = run(False)
-    assert logits0.shape == (2, 128 + 16, 32007) and torch.isfinite(logits0).all()
-    emb, am, lab = model.prepare_inputs_for_generation(inp)
-    assert am.shape == (2, 144) and bool((am == 1).all()) and bool((lab[:, :16] == -100).all())
-    assert torch.equal(lab[:, 16:], inp["labels"])
     loss1, logits1, g1 = run(True)
     assert torch.equal(loss0, loss1) and torch.equal(logits0, logits1)
     assert g0.keys() == g1.keys() and len(g0) > 290      # 32 x 9 layer tensors + embed / norm / head / alignment
@@ -326,20 +415,27 @@ def test_full_llama7b_size_independent_properties(dev, monkeypatch):
         assert torch.equal(g0[n], g1[n]), n
     model.llm.eval()
     model.llm.model.gradient_checkpointing = False
-    # reference formulation of the engine: no fused views, no fused attention
-    from macaw_llm_amd import engine as E
-    from macaw_llm_amd.modeling import LlamaDecoderLayer
-    monkeypatch.setattr(E, "flash_ok", lambda dtype, hd: False)
-    monkeypatch.setattr(LlamaDecoderLayer, "_fused_view", staticmethod(lambda ws: None))
-    with torch.no_grad():
-        ref = model(inputs=inp)
-    monkeypatch.undo()
-    emax, emean = _rel(logits0.cpu(), ref.logits.float().cpu())
-    print("full 7B fused-vs-unfused logits rel err (max/max, mean/mean):", emax, emean)
-    # two differently rounded bf16 paths through 32 layers: the one-layer figure (0.7 % of the mean
-    # magnitude, test above) grows like sqrt(32) -> ~4-6 % (measured 5.7 % mean, 6.2 % max/max)
-    assert emax <= 0.15 and emean <= 0.10, (emax, emean)
-    assert abs(loss0.item() - ref.loss.item()) <= 2e-2 * max(1.0, abs(ref.loss.item()))
+    model.zero_grad(set_to_none=True)
+    # oracle gradients (autograd through the restatement on the GPU) for tensors near the loss and
+    # at the bottom of the stack: fp32 = the reference value, eager bf16 = the yardstick
+    keys = ["llm.lm_head.weight", "llm.model.norm.weight", "llm.model.layers.31.mlp.down_proj.weight",
+            "llm.model.layers.31.self_attn.q_proj.weight", "llm.model.layers.0.mlp.gate_proj.weight",
+            "llm.model.layers.0.self_attn.v_proj.weight"]
+    grads = {}
+    for tag, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        sd = {k: v.to(dt) for k, v in _gpu_oracle_state(model).items()}
+        for k in keys:
+            sd[k] = sd[k].clone().requires_grad_(True)
+        fin = {k: (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}
+        restate.mm_forward(sd, fin, cfg)["loss"].backward()
+        grads[tag] = {k: sd[k].grad.float() for k in keys}
+        del sd
+    for k in keys:
+        want = grads["fp32"][k]
+        e_hip = (g0[k].float() - want).norm().item() / want.norm().item()
+        e_eag = (grads["bf16"][k] - want).norm().item() / want.norm().item()
+        print(f"grad {k}: rel L2 err vs fp32 oracle: HIP bf16 {e_hip:.3e}, eager bf16 {e_eag:.3e}")
+        assert e_hip <= 1.5 * e_eag + 1e-2, (k, e_hip, e_eag)
 
 
 def test_cfg4_sequence_2048_video_audio_text_full_model(dev):

@@ -15,9 +15,19 @@ from golden_util import load_case  # noqa: E402
 from oracle import configs  # noqa: E402
 
 
+@pytest.fixture(autouse=True)
+def _restore_auto_fuse():
+    from macaw_llm_amd import modeling as M
+    yield
+    M.AUTO_FUSE = True
+
+
 def build_model(cfg, state, dtype, dev, freeze_encoders=True, fuse=False):
+    """fuse=False pins the reference FORMULATION of the engine (three q/k/v GEMMs, two gate/up
+    GEMMs, unfused encoder projections): lazy fusion is switched off for the test."""
     from transformers import CLIPConfig, LlamaConfig, WhisperConfig
     from macaw_llm_amd import modeling as M
+    M.AUTO_FUSE = bool(fuse)
     mm = M.MM_LLMs_Config(clip_config=CLIPConfig(**cfg["clip"]), whisper_config=WhisperConfig(**cfg["whisper"]),
                           llm_config=LlamaConfig(**cfg["llama"]), **cfg["mm"])
     model = M.MM_LLMs(mm)
@@ -167,3 +177,70 @@ def test_generate_kv_cache_bf16_and_inference_flag(dev):
     inp["inference"] = True
     gen = model(inputs=inp)
     assert gen.dim() == 2 and gen.shape[0] == emb.shape[0] and gen.shape[1] <= 128
+
+
+def test_reference_construction_path_runs_the_fused_kernels(dev):
+    """run_clm_llms.py:478-497 builds the model as MM_LLMs(config) -> resize_token_embeddings ->
+    freeze -> Trainer .to(device / dtype).  That path must hit the SAME launches as
+    factory.build_model(fuse=True): q|k|v / gate|up (and the towers' q|k|v) are fused lazily at the
+    first forward and again after a later .to(); a reloaded state dict lands in the fused storage."""
+    from transformers import CLIPConfig, LlamaConfig, WhisperConfig
+    from macaw_llm_amd import modeling as M, ops
+    fx = load_case("micro_all")
+    cfg = configs.get(fx["config_name"])
+    mm = M.MM_LLMs_Config(clip_config=CLIPConfig(**cfg["clip"]), whisper_config=WhisperConfig(**cfg["whisper"]),
+                          llm_config=LlamaConfig(**cfg["llama"]), **cfg["mm"])
+    inp = to_dev(fx["inputs"], dev)
+
+    def launches(model):
+        ops.prof_begin()
+        out = model(inputs=inp)
+        out.loss.backward()
+        _, _, n = ops.prof_end()
+        model.zero_grad(set_to_none=True)
+        return n, out
+
+    model = M.MM_LLMs(mm)                                    # CPU, fp32, as the driver does
+    model.load_state_dict(fx["state"], strict=False)
+    model.llm.resize_token_embeddings(cfg["llama"]["vocab_size"])
+    for n, p in model.named_parameters():                    # run_clm_llms.py:390-393
+        p.requires_grad_("encoder" not in n)
+    model = model.to(dev).to(torch.bfloat16).eval()
+    l0 = model.llm.model.layers[0]
+    a0 = model.image_encoder.vision_model.encoder.layers[0].self_attn
+    assert l0._fused_view((l0.self_attn.q_proj.weight, l0.self_attn.k_proj.weight, l0.self_attn.v_proj.weight)) is None
+    n_auto, out_auto = launches(model)
+    assert all(v is not None for v in l0.fused_weights())
+    assert all(v is not None for v in M.fused_encoder_qkv(a0))
+    ref = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=True).eval()
+    n_fused, out_fused = launches(ref)
+    assert n_auto == n_fused
+    assert torch.equal(out_auto.logits, out_fused.logits)    # same kernels, same bits
+    M.AUTO_FUSE = False
+    n_unfused, _ = launches(build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=False).eval())
+    M.AUTO_FUSE = True
+    assert n_unfused > n_fused
+    # a later .to() gives every parameter its own storage again: fused again on the next forward
+    model = model.to(torch.float32).to(torch.bfloat16)
+    assert l0._fused_view((l0.mlp.gate_proj.weight, l0.mlp.up_proj.weight)) is None
+    n_again, out_again = launches(model)
+    assert n_again == n_fused and torch.equal(out_again.logits, out_fused.logits)
+    # reloading a checkpoint writes INTO the fused storage (no stale copies anywhere)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    key = "image_encoder.vision_model.encoder.layers.0.self_attn.k_proj.weight"
+    sd[key] = sd[key] * 0.5
+    model.load_state_dict(sd)
+    W3, _ = M.fused_encoder_qkv(a0)
+    E = a0.q_proj.weight.shape[0]
+    assert torch.equal(W3[E:2 * E], sd[key].to(dev))
+    _, out_mod = launches(model)
+    assert not torch.equal(out_mod.logits, out_fused.logits)
+
+
+def test_fp16_parameters_fail_with_the_remedy(dev):
+    from macaw_llm_amd.lib import MacawHipError
+    fx = load_case("micro_image")
+    cfg = configs.get(fx["config_name"])
+    model = build_model(cfg, fx["state"], torch.float16, dev, fuse=True).eval()
+    with pytest.raises(MacawHipError, match="bfloat16"):
+        model(inputs=to_dev(fx["inputs"], dev))

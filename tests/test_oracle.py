@@ -40,6 +40,29 @@ def test_restated_gradients_match_golden():
             assert abs(sd[name].grad.norm().item() - n) <= 1e-4 * max(n, 1e-3), name
 
 
+def test_restatement_matches_reference_at_real_7b_dimensions():
+    """tests/golden/real7b_layer.pt = one LLaMA-7B decoder layer + final norm + 512 lm_head rows
+    run by the REFERENCE's own classes (oracle/make_golden.py make_real7b_layer; weights from the
+    seeded recipe in oracle/inputs.py): the restatement must reproduce it at D = 4096, FF = 11008,
+    32 heads, with right padding -- forward and the gradient w.r.t. the layer input."""
+    import os
+    from golden_util import GOLDEN_DIR
+    fx = torch.load(os.path.join(GOLDEN_DIR, "real7b_layer.pt"), weights_only=False)
+    w = oin.real7b_layer_weights(fx["seed"], fx["head_rows"])
+    x, am = oin.real7b_layer_inputs(fx["seed"], fx["B"], fx["S"])
+    sd = {k.replace("layer.", "L."): v for k, v in w.items()}
+    B, S = fx["B"], fx["S"]
+    x = x.clone().requires_grad_(True)
+    mask = restate.decoder_mask(am, B, S, torch.float32, x.device)
+    cos, sin = restate.rotary_tables(128, 2048)
+    h = restate.llama_layer(sd, "L.", x, mask, torch.arange(S).unsqueeze(0), 32, 1e-6, cos, sin)
+    logits = torch.nn.functional.linear(restate.rms_norm(h, sd["norm.weight"], 1e-6), sd["lm_head.weight"])
+    (logits * oin.real7b_layer_cotangent(fx["seed"], B, S, fx["head_rows"])).sum().backward()
+    assert (h - fx["layer_out"]).abs().max().item() < 2e-5
+    assert (logits - fx["logits"]).abs().max().item() < 2e-5
+    assert (x.grad - fx["dx"]).abs().max().item() < 2e-5 * max(1.0, fx["dx"].abs().max().item())
+
+
 def test_positional_encoding_quirk():
     """exponent uses 2*i with i already stepping by 2 (non-textbook)."""
     a, b = restate.positional_encoding(16, 48), restate.positional_encoding_loop(16, 48)
