@@ -1,12 +1,18 @@
 #!/usr/bin/env python
 """Headline benchmark (BASELINE.json): multimodal samples/s, image + 30 s audio + 128-token
-instruction, forward + backward + AdamW step (+ gradient all-reduce for N > 1), CLIP-ViT-L/14 +
+instruction, forward + backward + AdamW step (+ gradient reduction for N > 1), CLIP-ViT-L/14 +
 Whisper-base + LLaMA-7B in bf16 on synthetic data — BASELINE cfg 3 at 32 samples per GPU
 (global 256 at 8 GPUs, weak scaling).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 5 --warmup 2                 # cfg 3 = the metric's config
+    python bench.py --config 2|4|5 ...                            # the other BASELINE.json configs
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+--config: 2 = image + text, B = 16 (S = 136); 3 = image + audio + text, 32 per GPU (S = 144);
+4 = video (6 frames) + audio + text at sequence 2048, 4 per GPU; 5 = LLaMA-13B backbone with the
+fp8 (e4m3) MFMA forward of the q|k|v and alignment K/V GEMMs, 32 per GPU, activation
+checkpointing on (one GPU holds the whole 13B training state: peak memory is printed).
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline     : dominant kernel = the bf16 MFMA GEMM (csrc/gemm.hip); achieved = algorithmic
@@ -35,22 +41,45 @@ import torch.distributed as dist  # noqa: E402
 TEXT_LEN = 128
 PER_GPU_BATCH = 32
 MFMA_BF16_PEAK = 2.5e15   # dense, /opt/skills/guides/MI355X_MICROARCH.md:42
-# algorithmic fwd+bwd FLOPs per sample, minimal formulation, encoders frozen
-ALG_TFLOP_PER_SAMPLE = 6.42
+# BASELINE.json configs 2-5 (config 1 is the CPU plumbing check).  alg_tf = algorithmic fwd+bwd
+# TFLOP per sample, minimal formulation, encoders frozen as the reference's driver always does
+# (5.997 / 6.42 / 94.3 - 2 x the frozen towers' forward / 12.07).
+CONFIGS = {
+    2: dict(model="real_7b", modalities=("images",), batch=16, text_len=128, seq=136, alg_tf=5.997,
+            fp8=False, ckpt=False,
+            workload="BASELINE cfg 2: CLIP-ViT-L/14 -> alignment -> LLaMA-7B, image + 128-token text (S=136), "
+                     "bf16, batch 16 per GPU"),
+    3: dict(model="real_7b", modalities=("images", "audios"), batch=32, text_len=128, seq=144, alg_tf=6.42,
+            fp8=False, ckpt=False,
+            workload="BASELINE cfg 3: CLIP-ViT-L/14 + Whisper-base + LLaMA-7B, image + 30 s audio + 128-token "
+                     "text (S=144)"),
+    4: dict(model="real_7b", modalities=("audios", "videos"), batch=4, text_len=2048 - 61, seq=2048, alg_tf=92.2,
+            fp8=False, ckpt=False,
+            workload="BASELINE cfg 4: 6 video frames (per-frame CLIP-ViT-L/14) + 30 s audio (Whisper-base) + text, "
+                     "LLaMA-7B at sequence length 2048, 4 samples per GPU"),
+    5: dict(model="real_13b", modalities=("images", "audios"), batch=32, text_len=128, seq=144, alg_tf=12.07,
+            fp8=True, ckpt=True,
+            workload="BASELINE cfg 5: LLaMA-13B backbone (D=5120, 40 layers), image + 30 s audio + 128-token text "
+                     "(S=144), fp8 (e4m3) MFMA forward of the q|k|v and alignment K/V GEMMs, activation "
+                     "checkpointing on, whole training state on one GPU"),
+}
 
 
 def pmc_gemm_traffic():
     """HBM-side bytes per mk_gemm launch from the committed rocprofv3 --pmc passes of this same
-    command (profiles/r01_step_traffic_pmc.csv: FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for
+    command (profiles/r02_step_traffic_pmc.csv: FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for
     gfx950, + WRITE_SIZE, separate passes, last step).  PMC cannot be collected inside a timed run,
     so the bench line carries the profiled figure; None if the profile is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_step_traffic_pmc.csv")
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    path = os.path.join(here, "r02_step_traffic_pmc.csv")
+    if not os.path.exists(path):
+        path = os.path.join(here, "r01_step_traffic_pmc.csv")
     try:
         gb, n = 0.0, 0
         with open(path) as f:
             for line in f:
                 c = line.strip().split(",")
-                if c[0].startswith("gemm_bf16_v2_kernel"):
+                if "gemm_bf16" in c[0]:
                     # the template argument list contains commas: the numeric columns are the last four
                     n += int(c[-4])
                     gb += float(c[-3]) + float(c[-2])
@@ -59,14 +88,23 @@ def pmc_gemm_traffic():
         return None
 
 
-def cpu_baseline(threads: int) -> dict:
+def cpu_baseline(threads: int, spec: dict) -> dict:
     """Reference algorithm on the host cores (oracle port), composed from real-dimension
-    components exactly as BASELINE.md §2 prescribes; bounded to ~20 s."""
+    components exactly as BASELINE.md §2 prescribes; bounded to ~20-30 s.  The alignment leg
+    times only the per-sample K/V projection of the token table (scores / softmax / PV / out-proj
+    omitted) and the towers run forward only: both err in the CPU's favour."""
     import torch.nn.functional as F
     from oracle import restate
+    from macaw_llm_amd.factory import baseline_config
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(0)
-    D, FF, H, S, V = 4096, 11008, 32, 144, 32007
+    mcfg = baseline_config(spec["model"])
+    ll = mcfg["llama"]
+    D, FF, H, V = ll["hidden_size"], ll["intermediate_size"], ll["num_attention_heads"], 32007
+    L, S = ll["num_hidden_layers"], spec["seq"]
+    mods = spec["modalities"]
+    n_clip = (1 if "images" in mods else 0) + (mcfg["mm"]["n_frames"] if "videos" in mods else 0)
+    n_wh = 1 if "audios" in mods else 0
 
     def rnd(*shape, s=0.02):
         return torch.randn(*shape, generator=g) * s
@@ -121,9 +159,7 @@ def cpu_baseline(threads: int) -> dict:
     t_align = timeit(kvproj, reps=1) * 8.0
     del E, Wkv
     # frozen encoders: forward only (run_clm_llms.py:390-393)
-    from macaw_llm_amd.factory import baseline_config
-    cfg = baseline_config("real_7b")
-    vc, wc = cfg["clip"]["vision_config"], cfg["whisper"]
+    vc, wc = mcfg["clip"]["vision_config"], mcfg["whisper"]
     csd = {}
     pv = "v."
     Ed, Fd = vc["hidden_size"], vc["intermediate_size"]
@@ -162,13 +198,14 @@ def cpu_baseline(threads: int) -> dict:
     mel = torch.randn(1, 80, 3000, generator=g)
     with torch.no_grad():
         t_wh = timeit(lambda: restate.whisper_encoder_forward(wsd, pw, mel, wc), reps=1)
-    total = 32 * t_layer + t_head + t_clip + t_wh + 2 * t_align
+    total = L * t_layer + t_head + n_clip * t_clip + n_wh * t_wh + len(mods) * t_align
     return dict(value=1.0 / total, unit="samples/s", cores=threads, kind="port",
                 sample=("composed from real-dimension components, B=1, fp32, reference formulation: "
-                        f"32 x LlamaDecoderLayer f+b ({t_layer:.3f}s each) + norm/lm_head/CE f+b ({t_head:.3f}s) "
-                        f"+ CLIP-L/14 fwd ({t_clip:.3f}s) + Whisper-base fwd ({t_wh:.3f}s) + 2 x per-sample "
-                        f"alignment K/V projection f+b ({t_align:.3f}s each; timed on 1/8 of the 32,007 table "
-                        "rows and scaled x8)"),
+                        f"{L} x LlamaDecoderLayer f+b at S={S} ({t_layer:.3f}s each) + norm/lm_head/CE f+b "
+                        f"({t_head:.3f}s) + {n_clip} x CLIP-L/14 fwd ({t_clip:.3f}s) + {n_wh} x Whisper-base fwd "
+                        f"({t_wh:.3f}s) + {len(mods)} x per-sample alignment K/V projection f+b ({t_align:.3f}s "
+                        "each; timed on 1/8 of the 32,007 table rows and scaled x8; scores/softmax/PV/out-proj "
+                        "not timed)"),
                 seconds_per_sample=total)
 
 
@@ -192,11 +229,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-per-gpu", type=int, default=PER_GPU_BATCH)
-    ap.add_argument("--model", default="real_7b")
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration (3 = the metric's configuration, the default)")
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="override the configuration's per-GPU batch")
+    ap.add_argument("--model", default=None, help="override the configuration's backbone (real_7b / real_13b)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fp8", action="store_true", help="BASELINE cfg 5 precision: q|k|v and alignment K/V "
-                    "forward GEMMs on the fp8 (e4m3) MFMA path; NOT the headline bf16 configuration")
+    ap.add_argument("--fp8", action="store_true", help="force the cfg 5 precision (q|k|v and alignment K/V "
+                    "forward GEMMs on the fp8 MFMA path) on another configuration")
+    ap.add_argument("--checkpoint", action="store_true", help="force activation checkpointing of the decoder layers")
     ap.add_argument("--layers", type=int, default=None, help="debug only: truncates the LLaMA stack "
                     "(the printed line is then marked invalid)")
     args = ap.parse_args()
@@ -224,20 +264,29 @@ def main():
     from macaw_llm_amd.factory import baseline_config, build_model, synthetic_inputs
     from macaw_llm_amd.optim import FusedAdamW
 
-    cfg = baseline_config(args.model)
+    spec = dict(CONFIGS[args.config])
+    if args.model:
+        spec["model"] = args.model
+    if args.batch_per_gpu:
+        spec["batch"] = args.batch_per_gpu
+    spec["fp8"] = spec["fp8"] or args.fp8
+    spec["ckpt"] = spec["ckpt"] or args.checkpoint
+    cfg = baseline_config(spec["model"])
     if args.layers is not None:
         cfg["llama"]["num_hidden_layers"] = args.layers
     model = build_model(cfg, dtype=torch.bfloat16, device=dev, seed=1234).train()
-    if args.fp8:
+    if spec["fp8"]:
         model.set_fp8(qkv=True, align=True)
+    if spec["ckpt"]:
+        model.llm.model.gradient_checkpointing = True     # modeling.py:474-489
     params = [p for p in model.parameters() if p.requires_grad]
     opt = FusedAdamW(params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
     runtime = OverlappedStep(params, opt, overlap=not os.environ.get("MACAW_NO_OVERLAP"),
                              overlap_optimizer=bool(os.environ.get("MACAW_OVERLAP_ADAMW")),
                              shard_optimizer=False if os.environ.get("MACAW_NO_SHARD") else None,
                              force_collectives=force_coll)
-    B = args.batch_per_gpu
-    inputs = synthetic_inputs(cfg, B, TEXT_LEN, modalities=("images", "audios"), seed=1 + rank, device=dev)
+    B = spec["batch"]
+    inputs = synthetic_inputs(cfg, B, spec["text_len"], modalities=spec["modalities"], seed=1 + rank, device=dev)
 
     def step():
         runtime.begin()                      # zero grads, advance Adam's step counter
@@ -254,19 +303,8 @@ def main():
 
     # one untimed SETUP step: materialises the optimizer state (fp32 master / m / v, 84 GB at 7B)
     # and the allocator pools, like building the model.  The W warm-up steps follow.
-    try:
-        step()
-    except Exception as e:  # N > 1 only: the ZeRO-1 collectives are the one path a 1-GPU pool cannot run
-        if not (world > 1 and runtime.shard):
-            raise
-        print(f"[bench] rank {rank}: sharded step failed ({e!r}); falling back to all-reduce + replicated "
-              "AdamW", file=sys.stderr, flush=True)
-        runtime.remove()
-        opt = FusedAdamW(params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
-        runtime = OverlappedStep(params, opt, overlap=not os.environ.get("MACAW_NO_OVERLAP"),
-                                 overlap_optimizer=bool(os.environ.get("MACAW_OVERLAP_ADAMW")),
-                                 shard_optimizer=False)
-        step()
+    # (a failure of the sharded N > 1 path is an error: a degraded run must not pass as ZeRO-1)
+    step()
     for _ in range(args.warmup):
         l0 = step()
         if os.environ.get("MACAW_BENCH_VERBOSE") and rank == 0:
@@ -281,7 +319,9 @@ def main():
     dt = time.perf_counter() - t0
     if os.environ.get("MACAW_GEMM_REPORT") and rank == 0:
         ops.prof_report(os.environ["MACAW_GEMM_REPORT"])
+    att_f, att_b = ops.prof_sum(1), ops.prof_sum(2)
     gemm_ms, gemm_flops, gemm_n = ops.prof_end()
+    peak_mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -290,39 +330,51 @@ def main():
     value = world * B / (dt / args.steps)
 
     if rank == 0:
-        S = TEXT_LEN + 16
+        S = spec["seq"]
+        alg_tf = spec["alg_tf"]
         achieved = gemm_flops / (gemm_ms * 1e-3) if gemm_ms > 0 else 0.0
+
+        def rate(t):      # (ms, flops, launches) -> dict
+            ms, fl, n = t
+            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {"achieved": round(tf, 1), "frac": round(tf * 1e12 / MFMA_BF16_PEAK, 4), "ms_per_step": round(ms, 3),
+                    "launches_per_step": n}
         line = {
             "metric": "multimodal samples/sec (img+audio+128 tok) fwd+bwd",
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if not args.fp8 else "bf16 + fp8(e4m3) forward of q|k|v and alignment K/V GEMMs",
+            "dtype": "bf16" if not spec["fp8"] else "bf16 + fp8(e4m3) forward of q|k|v and alignment K/V GEMMs",
             "data": "synthetic",
-            "config": {"workload": ("BASELINE cfg 3: CLIP-ViT-L/14 + Whisper-base + LLaMA-7B, image + 30 s "
-                                    "audio + 128-token text (S=144), fwd+bwd+fused AdamW, encoders frozen as "
+            "config": {"workload": (spec["workload"] + "; fwd+bwd+fused AdamW, encoders frozen as "
                                     "run_clm_llms.py:390-393, alignment-attention dropout on"),
+                       "baseline_config": args.config,
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": S,
                        "parallelism": f"dp{world}" + (" + ZeRO-1 optimizer shards (reduce-scatter / "
                                                       "all-gather behind backward)" if runtime.shard else ""),
-                       "setup_steps": 1,
+                       "setup_steps": 1, "activation_checkpointing": bool(spec["ckpt"]),
+                       "peak_mem_gib": round(peak_mem, 1),
                        "loss": round(float(loss.detach()), 4)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_v2_kernel: all mk_gemm launches of the step (csrc/gemm.hip)",
+            "roofline": {"bound": "mfma", "kernel": "all mk_gemm launches of the step: gemm_bf16_v7_kernel (256x256, "
+                                                    "csrc/gemm_v7.hip) + gemm_bf16_v2_kernel (128x128, csrc/gemm.hip)",
                          "achieved": round(achieved / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK, 4),
                          "traffic": pmc_gemm_traffic(),
-                         "traffic_note": "HBM-side bytes per mk_gemm launch (rocprofv3 PMC, profiles/"
-                                         "r01_step_traffic_pmc.csv; includes Infinity-Cache hits)",
+                         "traffic_note": "HBM-side bytes per mk_gemm launch of the cfg 3 step (rocprofv3 PMC, "
+                                         "profiles/r02_step_traffic_pmc.csv; includes Infinity-Cache hits)",
                          "launches_per_step": gemm_n, "gemm_ms_per_step": round(gemm_ms, 3),
                          "gemm_tflop_per_step": round(gemm_flops / 1e12, 2),
-                         "whole_step_model_tflops": round(value / world * ALG_TFLOP_PER_SAMPLE, 1),
-                         "whole_step_frac": round(value / world * ALG_TFLOP_PER_SAMPLE * 1e12 / MFMA_BF16_PEAK, 4)},
+                         "whole_step_model_tflops": round(value / world * alg_tf, 1),
+                         "whole_step_frac": round(value / world * alg_tf * 1e12 / MFMA_BF16_PEAK, 4),
+                         # fused attention kernels (csrc/attention.hip), algorithmic FLOPs (causal =
+                         # lower triangle), same live HIP-event timing
+                         "attention_fwd": rate(att_f), "attention_bwd": rate(att_b)},
         }
         if args.layers is not None:
             line["invalid"] = f"debug run with --layers {args.layers}"
         if world == 1 and not args.no_cpu_baseline:
             try:
-                cb = cpu_baseline(host_cores())
+                cb = cpu_baseline(host_cores(), spec)
                 line["cpu_baseline"] = cb
                 line["gpu_over_cpu"] = round(value / cb["value"], 1)
             except Exception as e:  # the baseline leg must never take the GPU number down with it

@@ -96,6 +96,10 @@ int mk_gemm_set_cfg(int cfg);
  * (bench.py roofline): begin, run, then end() synchronises and returns the sums. */
 int mk_prof_begin(void);
 int mk_prof_end(double* total_ms, double* total_flops, int64_t* launches);
+/* the same sums for one launch kind since mk_prof_begin (0 = mk_gemm, 1 = mk_flash_attn_fwd,
+ * 2 = mk_flash_attn_bwd; attention FLOPs are algorithmic: causal = lower triangle); call before
+ * mk_prof_end */
+int mk_prof_sum(int kind, double* total_ms, double* total_flops, int64_t* launches);
 /* per-shape CSV breakdown (host path) of the launches since mk_prof_begin; call before end */
 int mk_prof_report(const char* path);
 

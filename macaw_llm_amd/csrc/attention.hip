@@ -233,6 +233,10 @@ extern "C" int mk_flash_attn_fwd(const void* q, const void* k, const void* v, vo
   a.scale = scale;
   dim3 grid(H, B, mk_cdiv(Lq, 128)), block(256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // algorithmic FLOPs: QK^T and PV, 2 * Lq * Lk * hd each per (b, h); causal counts the lower
+  // triangle only (what a masked dense formulation would not skip is not work)
+  const double pairs = causal ? ((double)Lq * Lk - 0.5 * (double)min(Lq, Lk) * (min(Lq, Lk) - 1)) : (double)Lq * Lk;
+  const int prof = mkp::begin(st, 1, 4.0 * pairs * hd * B * H, Lq, Lk, hd, B * H, causal, 0);
   if (hd == 128) {
     if (causal) MK_LAUNCH((flash_fwd_kernel<128, true>), grid, block, 0, st, a);
     else MK_LAUNCH((flash_fwd_kernel<128, false>), grid, block, 0, st, a);
@@ -240,6 +244,7 @@ extern "C" int mk_flash_attn_fwd(const void* q, const void* k, const void* v, vo
     if (causal) MK_LAUNCH((flash_fwd_kernel<64, true>), grid, block, 0, st, a);
     else MK_LAUNCH((flash_fwd_kernel<64, false>), grid, block, 0, st, a);
   }
+  mkp::end(prof, st);
   return mk_check_launch();
 }
 
@@ -632,6 +637,10 @@ extern "C" int mk_flash_attn_bwd(const void* q, const void* k, const void* v, co
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long rows = (long)B * H * Lq;
   dim3 gq(H, B, mk_cdiv(Lq, 128)), gk(H, B, mk_cdiv(Lk, 128)), block(256);
+  // backward: dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q (4 products) + the recomputed
+  // QK^T: counted as the 4 algorithmic ones = 2x the forward
+  const double pairs = causal ? ((double)Lq * Lk - 0.5 * (double)min(Lq, Lk) * (min(Lq, Lk) - 1)) : (double)Lq * Lk;
+  const int prof = mkp::begin(st, 2, 8.0 * pairs * hd * B * H, Lq, Lk, hd, B * H, causal, 0);
 #define MK_FB(HDV, CZ)                                                                         \
   do {                                                                                         \
     MK_LAUNCH((flash_bwd_prep_kernel<HDV>), dim3((unsigned)((rows * (HDV / 8) + 255) / 256)), block, 0, st, a); \
@@ -641,5 +650,6 @@ extern "C" int mk_flash_attn_bwd(const void* q, const void* k, const void* v, co
   if (hd == 128) { if (causal) MK_FB(128, true); else MK_FB(128, false); }
   else { if (causal) MK_FB(64, true); else MK_FB(64, false); }
 #undef MK_FB
+  mkp::end(prof, st);
   return mk_check_launch();
 }

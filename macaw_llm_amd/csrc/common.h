@@ -148,3 +148,10 @@ MK_DEV bool mk_keep(uint64_t seed, uint64_t idx, uint32_t keep_threshold) {
 }
 
 static inline int mk_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// live launch profiler (implemented in gemm.hip): see mk_prof_begin / mk_prof_sum
+namespace mkp {
+int begin(hipStream_t st, int kind, double flops, int M, int N, int K, int nb, int layout, int cfg);
+void set_cfg(int idx, int cfg);
+void end(int idx, hipStream_t st);
+}

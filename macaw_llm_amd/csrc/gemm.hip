@@ -783,14 +783,32 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 
 // ---------------------------------------------------------------- profiler --
-// Optional per-launch HIP-event timing of mk_gemm on the launch stream, used by bench.py
-// for the `roofline` figure (kernel time measured live, same stream as the kernel).
+// Optional per-launch HIP-event timing on the launch stream, used by bench.py for the `roofline`
+// figures (kernel time measured live, same stream as the kernel).  kind 0 = mk_gemm, 1 = fused
+// attention forward, 2 = fused attention backward (csrc/attention.hip calls mkp::begin / end).
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, nb, layout, cfg; };
+struct ProfRec { hipEvent_t a, b; double flops; int kind, M, N, K, nb, layout, cfg; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 }  // namespace
+
+namespace mkp {
+bool on() { return g_prof_on; }
+// returns an index into the record list (or -1 when profiling is off); the start event is recorded
+int begin(hipStream_t st, int kind, double flops, int M, int N, int K, int nb, int layout, int cfg) {
+  if (!g_prof_on) return -1;
+  ProfRec rec{};
+  if (!g_prof_pool.empty()) { rec.a = g_prof_pool.back().first; rec.b = g_prof_pool.back().second; g_prof_pool.pop_back(); }
+  else { (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b); }
+  rec.flops = flops; rec.kind = kind; rec.M = M; rec.N = N; rec.K = K; rec.nb = nb; rec.layout = layout; rec.cfg = cfg;
+  (void)hipEventRecord(rec.a, st);
+  g_prof.push_back(rec);
+  return (int)g_prof.size() - 1;
+}
+void set_cfg(int idx, int cfg) { if (idx >= 0) g_prof[idx].cfg = cfg; }
+void end(int idx, hipStream_t st) { if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, st); }
+}  // namespace mkp
 
 extern "C" int mk_prof_begin(void) {
   for (auto& r : g_prof) g_prof_pool.emplace_back(r.a, r.b);
@@ -798,29 +816,36 @@ extern "C" int mk_prof_begin(void) {
   g_prof_on = true;
   return MK_OK;
 }
-// Synchronises, sums (elapsed ms, flops, launches) over every mk_gemm since mk_prof_begin.
-extern "C" int mk_prof_end(double* total_ms, double* total_flops, int64_t* launches) {
-  g_prof_on = false;
+// Synchronises, sums (elapsed ms, flops, launches) over every launch of `kind` since mk_prof_begin.
+extern "C" int mk_prof_sum(int kind, double* total_ms, double* total_flops, int64_t* launches) {
   double ms = 0.0, fl = 0.0;
+  int64_t n = 0;
   for (auto& r : g_prof) {
+    if (r.kind != kind) continue;
     if (hipEventSynchronize(r.b) != hipSuccess) return MK_ERR_LAUNCH;
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return MK_ERR_LAUNCH;
     ms += t;
     fl += r.flops;
+    ++n;
   }
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
-  if (launches) *launches = (int64_t)g_prof.size();
+  if (launches) *launches = n;
   return MK_OK;
+}
+// mk_gemm launches (kind 0) since mk_prof_begin; stops recording.
+extern "C" int mk_prof_end(double* total_ms, double* total_flops, int64_t* launches) {
+  g_prof_on = false;
+  return mk_prof_sum(0, total_ms, total_flops, launches);
 }
 
 // Per-shape breakdown of the launches since mk_prof_begin, written as CSV
-// (M,N,K,batch,layout,cfg,launches,total_ms,tflops).  Call before mk_prof_end.
+// (kind,M,N,K,batch,layout,cfg,launches,total_ms,tflops).  Call before mk_prof_end.
 extern "C" int mk_prof_report(const char* path) {
   FILE* f = fopen(path, "w");
   if (!f) return MK_ERR_BAD_ARG;
-  struct Agg { int M, N, K, nb, layout, cfg; long n; double ms, fl; };
+  struct Agg { int kind, M, N, K, nb, layout, cfg; long n; double ms, fl; };
   std::vector<Agg> aggs;
   for (auto& r : g_prof) {
     if (hipEventSynchronize(r.b) != hipSuccess) { fclose(f); return MK_ERR_LAUNCH; }
@@ -828,15 +853,15 @@ extern "C" int mk_prof_report(const char* path) {
     (void)hipEventElapsedTime(&t, r.a, r.b);
     bool found = false;
     for (auto& a : aggs)
-      if (a.M == r.M && a.N == r.N && a.K == r.K && a.nb == r.nb && a.layout == r.layout && a.cfg == r.cfg) {
+      if (a.kind == r.kind && a.M == r.M && a.N == r.N && a.K == r.K && a.nb == r.nb && a.layout == r.layout && a.cfg == r.cfg) {
         a.n++; a.ms += t; a.fl += r.flops; found = true; break;
       }
-    if (!found) aggs.push_back({r.M, r.N, r.K, r.nb, r.layout, r.cfg, 1, (double)t, r.flops});
+    if (!found) aggs.push_back({r.kind, r.M, r.N, r.K, r.nb, r.layout, r.cfg, 1, (double)t, r.flops});
   }
-  fprintf(f, "M,N,K,batch,layout,cfg,launches,total_ms,tflops\n");
+  fprintf(f, "kind,M,N,K,batch,layout,cfg,launches,total_ms,tflops\n");
   for (auto& a : aggs)
-    fprintf(f, "%d,%d,%d,%d,%d,%d,%ld,%.4f,%.1f\n", a.M, a.N, a.K, a.nb, a.layout, a.cfg, a.n, a.ms,
-            a.ms > 0 ? a.fl / (a.ms * 1e-3) / 1e12 : 0.0);
+    fprintf(f, "%s,%d,%d,%d,%d,%d,%d,%ld,%.4f,%.1f\n", a.kind == 0 ? "gemm" : a.kind == 1 ? "attn_fwd" : "attn_bwd",
+            a.M, a.N, a.K, a.nb, a.layout, a.cfg, a.n, a.ms, a.ms > 0 ? a.fl / (a.ms * 1e-3) / 1e12 : 0.0);
   fclose(f);
   return MK_OK;
 }
@@ -922,24 +947,17 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
   g.alpha = d->alpha; g.bias_mode = d->bias_mode; g.act = d->act; g.accumulate = d->accumulate;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nbatch = d->nb1 * d->nb2;
-  ProfRec rec{};
-  if (g_prof_on) {
-    if (!g_prof_pool.empty()) { rec.a = g_prof_pool.back().first; rec.b = g_prof_pool.back().second; g_prof_pool.pop_back(); }
-    else { (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b); }
-    rec.flops = 2.0 * d->M * d->N * d->K * nbatch * (fp8 ? 2 : 1);
-    rec.M = d->M; rec.N = d->N; rec.K = d->K * (fp8 ? 2 : 1); rec.nb = nbatch;
-    rec.layout = d->a_red_major * 2 + d->b_red_major; rec.cfg = -1;
-    (void)hipEventRecord(rec.a, st);
-  }
+  const int prof = mkp::begin(st, 0, 2.0 * d->M * d->N * d->K * nbatch * (fp8 ? 2 : 1), d->M, d->N,
+                              d->K * (fp8 ? 2 : 1), nbatch, d->a_red_major * 2 + d->b_red_major, -1);
   // (measured on generate(): B = 1: 7.5 -> 6.1 ms/token, B = 8: 7.2 -> 6.5; at B = 32 the 32 distinct
   // token rows re-read per workgroup cost more than the tile kernel's wasted rows: 8.6 vs 8.0)
   static const int skinny_max = [] { const char* e = getenv("MK_GEMM_SKINNY_MAX_M"); return e ? atoi(e) : 16; }();
   if (d->dtype == MK_BF16 && !fp8 && d->M <= 32 && d->M <= skinny_max && !d->a_red_major && !d->b_red_major && nbatch == 1 &&
       (d->K % 64) == 0 && (d->lda % 8) == 0 && (d->ldb % 8) == 0 && aligned16(d->A) && aligned16(d->B) &&
       !getenv("MK_GEMM_NO_SKINNY")) {
-    rec.cfg = 12;
+    mkp::set_cfg(prof, 12);
     MK_LAUNCH((gemm_skinny_kernel<8>), dim3(mk_cdiv(d->N, 32)), dim3(512), 0, st, g);
-    if (g_prof_on) { (void)hipEventRecord(rec.b, st); g_prof.push_back(rec); }
+    mkp::end(prof, st);
     return mk_check_launch();
   }
   if (d->dtype == MK_BF16) {
@@ -989,7 +1007,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     // faster than BK = 64 on the 128x128 tile; K-major operands would degrade to 64-B segments.
     if (cfg == 5 && d->a_red_major && d->b_red_major && !getenv("MK_GEMM_NO_BK32")) cfg = 7;
     const int bkv = cfg == 7 ? 32 : BK;
-    rec.cfg = cfg;
+    mkp::set_cfg(prof, cfg);
     const bool t256 = cfg == 11;
     const int bm = t256 ? 256 : 128;
     const int bn = t256 ? 256 : BN;
@@ -1081,7 +1099,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
   } while (0)
     if (t256) {
       const int rc = mkg::launch_v7(g, d->a_red_major != 0, d->b_red_major != 0, grid, st);
-      if (g_prof_on) { (void)hipEventRecord(rec.b, st); g_prof.push_back(rec); }
+      mkp::end(prof, st);
       return rc;
     }
     if (fp8) MK_V2F8();
@@ -1108,7 +1126,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     else
       MK_LAUNCH((gemm_f32_kernel<true, true>), grid, block, 0, st, g);
   }
-  if (g_prof_on) { (void)hipEventRecord(rec.b, st); g_prof.push_back(rec); }
+  mkp::end(prof, st);
   return mk_check_launch();
 }
 

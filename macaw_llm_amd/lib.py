@@ -56,6 +56,7 @@ SIGNATURES = {
     "mk_gemm_set_cfg": [_i32],
     "mk_prof_begin": [],
     "mk_prof_end": [_vp, _vp, _vp],
+    "mk_prof_sum": [_i32, _vp, _vp, _vp],
     "mk_prof_report": [C.c_char_p],
     "mk_transpose": [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _vp],
     "mk_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp],

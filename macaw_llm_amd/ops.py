@@ -526,6 +526,14 @@ def prof_report(path: str):
     _L.check(_L.load().mk_prof_report(path.encode()), "mk_prof_report")
 
 
+def prof_sum(kind: int):
+    """(total_ms, total_flops, launches) of one launch kind since prof_begin: 0 GEMM, 1 fused
+    attention forward, 2 fused attention backward.  Call before prof_end."""
+    ms, fl, n = C.c_double(0), C.c_double(0), C.c_int64(0)
+    _L.check(_L.load().mk_prof_sum(kind, C.byref(ms), C.byref(fl), C.byref(n)), "mk_prof_sum")
+    return ms.value, fl.value, n.value
+
+
 def prof_end():
     """returns (total_ms, total_flops, launches) of the mk_gemm launches since prof_begin"""
     ms, fl, n = C.c_double(0), C.c_double(0), C.c_int64(0)
