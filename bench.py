@@ -281,10 +281,20 @@ def main():
         model.llm.model.gradient_checkpointing = True     # modeling.py:474-489
     params = [p for p in model.parameters() if p.requires_grad]
     opt = FusedAdamW(params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
-    runtime = OverlappedStep(params, opt, overlap=not os.environ.get("MACAW_NO_OVERLAP"),
-                             overlap_optimizer=bool(os.environ.get("MACAW_OVERLAP_ADAMW")),
-                             shard_optimizer=False if os.environ.get("MACAW_NO_SHARD") else None,
-                             force_collectives=force_coll)
+    # N > 1: flat-bucket ZeRO-1 (macaw_llm_amd/bucketed.py: one reduce-scatter + one all-gather per
+    # ~768 MiB bucket behind the backward).  N = 1: the per-tensor step (no collectives, one
+    # multi-tensor AdamW launch); MACAW_BUCKETED=1 / MACAW_FORCE_COLLECTIVES=1 run the bucketed
+    # path on one GPU (the latter through a 1-rank RCCL group: software overhead of the N > 1 path)
+    bucketed = world > 1 or force_coll or bool(os.environ.get("MACAW_BUCKETED"))
+    if bucketed:
+        from macaw_llm_amd.bucketed import BucketedStep
+        runtime = BucketedStep(params, opt, overlap=not os.environ.get("MACAW_NO_OVERLAP"),
+                               force_collectives=force_coll,
+                               bucket_bytes=int(os.environ.get("MACAW_BUCKET_MB", "768")) << 20)
+    else:
+        runtime = OverlappedStep(params, opt, overlap=not os.environ.get("MACAW_NO_OVERLAP"),
+                                 overlap_optimizer=bool(os.environ.get("MACAW_OVERLAP_ADAMW")),
+                                 shard_optimizer=False, force_collectives=False)
     B = spec["batch"]
     inputs = synthetic_inputs(cfg, B, spec["text_len"], modalities=spec["modalities"], seed=1 + rank, device=dev)
 
@@ -350,8 +360,7 @@ def main():
                                     "run_clm_llms.py:390-393, alignment-attention dropout on"),
                        "baseline_config": args.config,
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": S,
-                       "parallelism": f"dp{world}" + (" + ZeRO-1 optimizer shards (reduce-scatter / "
-                                                      "all-gather behind backward)" if runtime.shard else ""),
+                       "parallelism": f"dp{world}" + (": " + runtime.describe() if bucketed else ""),
                        "setup_steps": 1, "activation_checkpointing": bool(spec["ckpt"]),
                        "peak_mem_gib": round(peak_mem, 1),
                        "loss": round(float(loss.detach()), 4)},

@@ -165,6 +165,11 @@ int mk_add(const void* a, const void* b, void* y, int64_t n, int64_t period, int
 int mk_cast(const void* in, int32_t in_dtype, void* out, int32_t out_dtype, int64_t n,
             void* stream);
 int mk_fill(void* p, float v, int64_t n, int32_t dtype, void* stream);
+/* out[0] (+)= sum_i x[i]^2 in fp32, deterministic (global gradient norm for clipping: the
+ * reference trains with HF max_grad_norm / DeepSpeed gradient_clipping, train.sh + configs/).
+ * ws: f32 [1024] scratch; x 16-byte aligned. */
+int mk_sumsq(const void* x, int64_t n, float* ws, float* out, int32_t accumulate, int32_t dtype,
+             void* stream);
 /* dst[z][r][0:cols] = src[z][r][0:cols] (pitched rows, batch strides; s_src = 0 broadcasts):
  * the torch.cat / slice / repeat plumbing of modeling.py:974-1046 without eager kernels. */
 int mk_copy2d(const void* src, void* dst, int32_t rows, int32_t cols, int64_t ld_src,

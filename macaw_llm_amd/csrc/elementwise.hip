@@ -3,6 +3,7 @@
 // All use 16-byte vector access on the fast path (cdna_hip_programming.md G13)
 // and grid-stride loops capped at 256 CUs x 8 blocks.
 #include "common.h"
+#include <algorithm>
 #include "../../include/macaw_hip.h"
 
 namespace {
@@ -484,6 +485,48 @@ extern "C" int mk_add(const void* a, const void* b, void* y, int64_t n, int64_t 
                                           (const T*)a, (const T*)b, (T*)y, (long)n, (long)period));
   return mk_check_launch();
 }
+// ---- sum of squares (global gradient norm for clipping: HF max_grad_norm / DeepSpeed
+// gradient_clipping in the reference's recipe).  Deterministic: fixed partition into <= 1024
+// block partials in fp32, then one block sums them in index order.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const T* x, long n, float* partial) {
+  __shared__ float red[16];
+  constexpr int N = VecIO<T>::N;
+  const long nvec = n / N;
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    float v[N];
+    VecIO<T>::load(x + i * N, v);
+#pragma unroll
+    for (int e = 0; e < N; ++e) s += v[e] * v[e];
+  }
+  if (blockIdx.x == 0)
+    for (long i = nvec * N + threadIdx.x; i < n; i += 256) { const float v = to_f32<T>(x[i]); s += v * v; }
+  s = block_sum<256>(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* partial, int nblk, float* out,
+                                                          int accumulate) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
+  s = block_sum<256>(s, red);
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
+}
+}  // namespace
+// out[0] (+)= sum x[i]^2 in fp32; ws: f32 [1024] scratch; x 16-byte aligned
+extern "C" int mk_sumsq(const void* x, int64_t n, float* ws, float* out, int32_t accumulate,
+                        int32_t dtype, void* stream) {
+  if (!x || !ws || !out || n <= 0) return MK_ERR_BAD_ARG;
+  if (reinterpret_cast<uintptr_t>(x) & 15) return MK_ERR_UNSUPPORTED;
+  const int nblk = (int)std::min<long>(1024, (n + 8191) / 8192);
+  MK_DISPATCH_T(dtype, MK_LAUNCH((sumsq_partial_kernel<T>), dim3(nblk), dim3(256), 0, MK_ST, (const T*)x,
+                                 (long)n, ws));
+  MK_LAUNCH(sumsq_final_kernel, dim3(1), dim3(256), 0, MK_ST, (const float*)ws, nblk, out, (int)accumulate);
+  return mk_check_launch();
+}
+
 extern "C" int mk_fill(void* p, float v, int64_t n, int32_t dtype, void* stream) {
   if (!p || n <= 0) return MK_ERR_BAD_ARG;
   if (dtype == MK_F16) {   // fp16 only carries the reference's `.half()` inputs (llm_trainer.py:366)

@@ -215,14 +215,14 @@ class LlamaLayerFn(torch.autograd.Function):
         dout2 = _c2(dout, M, D)
         # ---- MLP
         da = ops.linear_dx(dout2, wd)
-        dwd = ops.linear_dw(dout2, a) if need[13] else None
+        dwd = ops.linear_dw(dout2, a, w=wd) if need[13] else None
         dwg = dwu = None
         if gu is not None:
             dgu = ops.swiglu2d_bwd(gu, da, FF)
             del da
             dy2 = ops.linear_dx(dgu, wgu)
             if need[11] or need[12]:
-                dwgu = ops.linear_dw(dgu, y2)                  # [2FF, D]
+                dwgu = ops.linear_dw(dgu, y2, w=wgu)           # [2FF, D]
                 dwg, dwu = dwgu[:FF], dwgu[FF:]
             del dgu
         else:
@@ -236,7 +236,7 @@ class LlamaLayerFn(torch.autograd.Function):
         dh1, dln2 = ops.rmsnorm_bwd(dy2, h1, ln2, rstd2, dres=dout2)
         # ---- attention
         datt = ops.linear_dx(dh1, wo)
-        dwo = ops.linear_dw(dh1, att) if need[10] else None
+        dwo = ops.linear_dw(dh1, att, w=wo) if need[10] else None
         ldq = q.stride(0)
         if wqkv is not None:
             dqkv = torch.empty((M, 3 * D), dtype=q.dtype, device=q.device)
@@ -261,7 +261,7 @@ class LlamaLayerFn(torch.autograd.Function):
         if wqkv is not None:
             dy1 = ops.linear_dx(dqkv, wqkv)
             if need[7] or need[8] or need[9]:
-                dwqkv = ops.linear_dw(dqkv, y1)                # [3D, D]
+                dwqkv = ops.linear_dw(dqkv, y1, w=wqkv)        # [3D, D]
                 dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]
         else:
             dy1 = ops.linear_dx(dq, wq)
@@ -379,7 +379,7 @@ class LMHeadLossFn(torch.autograd.Function):
         # the pad columns [V, ldv) of dl are zero (ce_bwd writes the whole pitch, `ext` is
         # zero-filled): the K = V reduction of dx runs on the tile kernels over the padded width
         dy = ops.linear_dx(dlv, lm_w, dy_pad_zero=True)
-        dlm = ops.linear_dw(dlv, y) if need[2] else None
+        dlm = ops.linear_dw(dlv, y, w=lm_w) if need[2] else None
         dh, dnw = ops.rmsnorm_bwd(dy, h2, norm_w, rstd)
         return dh.view(B, S, D), (dnw if need[1] else None), dlm, None, None
 

@@ -75,6 +75,7 @@ SIGNATURES = {
     "mk_add": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "mk_cast": [_vp, _i32, _vp, _i32, _i64, _vp],
     "mk_fill": [_vp, _f32, _i64, _i32, _vp],
+    "mk_sumsq": [_vp, _i64, _vp, _vp, _i32, _i32, _vp],
     "mk_copy2d": [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _vp],
     "mk_embedding_fwd": [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp],
     "mk_embedding_bwd": [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp],

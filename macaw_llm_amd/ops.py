@@ -165,10 +165,30 @@ def linear_dx(dy, W, out=None, accumulate=False, residual=None, dy_pad_zero=Fals
     return out
 
 
-def linear_dw(dy, x, out=None, accumulate=False):
-    """dW[N,K] = dy[M,N]^T @ x[M,K]  (both operands red-major)"""
+# Weight-gradient destinations (bucketed.BucketedStep): (data_ptr, numel) of a weight (or of a fused
+# q|k|v / gate|up view) -> the view of the flat gradient bucket its dW is written to, so that
+# the grad-weight GEMM stores straight into the buffer the collective reads (no copy, no per-step
+# gradient allocation).  Empty = every dW gets a fresh tensor (the default).
+GRAD_DST = {}
+
+
+def grad_dst(w):
+    """registered destination for dW of weight `w` (same shape), else None"""
+    if not GRAD_DST or w is None:
+        return None
+    d = GRAD_DST.get((w.data_ptr(), w.numel()))
+    if d is not None and d.shape == w.shape and d.dtype == w.dtype:
+        return d
+    return None
+
+
+def linear_dw(dy, x, out=None, accumulate=False, w=None):
+    """dW[N,K] = dy[M,N]^T @ x[M,K]  (both operands red-major); `w` = the weight this is the
+    gradient of (looked up in GRAD_DST when no explicit `out` is given)"""
     M, N = dy.shape
     K = x.shape[1]
+    if out is None and not accumulate:
+        out = grad_dst(w)
     if out is None:
         out = torch.empty((N, K), dtype=dy.dtype, device=dy.device)
     gemm_raw(dy, x, out, N, K, M, _rowmajor(dy), _rowmajor(x), _rowmajor(out), a_red=True,
@@ -355,6 +375,22 @@ def fill_(x, v):
     lib = _L.load()
     _L.check(lib.mk_fill(_p(x), float(v), x.numel(), dt(x), _st()), "mk_fill")
     return x
+
+
+_SUMSQ_WS = {}
+
+
+def sumsq(x, out=None, accumulate=False):
+    """out[0] (+)= sum x^2 (fp32, deterministic); x contiguous / 16-byte aligned"""
+    lib = _L.load()
+    ws = _SUMSQ_WS.get(x.device)
+    if ws is None:
+        ws = _SUMSQ_WS[x.device] = torch.empty(1024, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        accumulate = False
+    _L.check(lib.mk_sumsq(_p(x), x.numel(), _p(ws), _p(out), int(accumulate), dt(x), _st()), "mk_sumsq")
+    return out
 
 
 def copy2d(src, dst, rows, cols, ld_src, ld_dst, batch=1, s_src=0, s_dst=0, src_off=0, dst_off=0):

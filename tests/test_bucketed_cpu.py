@@ -1,0 +1,184 @@
+"""macaw_llm_amd.bucketed.BucketedStep over gloo on CPU, world 2 and world 8: flat buckets,
+reduce-scatter -> owner updates its slice -> in-place all-gather, parameters whose sizes are not
+multiples of 8 * world, fused runs kept adjacent, parameters without gradient, gradient
+accumulation, global-norm clipping.  The optimizer is a stand-in with FusedAdamW's interface
+(the real kernel needs the GPU: tests/test_train_gpu.py)."""
+import math
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class ShardSGD:
+    """FusedAdamW's interface (step_count, lr, step_shard) with plain SGD arithmetic"""
+
+    def __init__(self, lr=0.5):
+        self.step_count = 0
+        self.lr = lr
+        self.calls = 0
+
+    def step_shard(self, key, w, g, grad_scale=1.0):
+        self.calls += 1
+        idx, lo, n = key
+        assert w.numel() == g.numel() == n
+        w -= self.lr * grad_scale * g
+
+
+class FusedFn(torch.autograd.Function):
+    """two parameters that are row slices of ONE buffer, gradients returned as row slices of one
+    buffer too (the fused q|k|v layout of the engine)"""
+
+    @staticmethod
+    def forward(ctx, a, b, s):
+        ctx.s = s
+        return (a.sum() + 2 * b.sum()) * s
+
+    @staticmethod
+    def backward(ctx, dy):
+        gfull = torch.empty(48, 16)
+        gfull[:16] = ctx.s
+        gfull[16:] = 2 * ctx.s
+        gfull *= (torch.arange(768.).view(48, 16) / 768 + 1) * dy
+        return gfull[:16], gfull[16:], None
+
+
+def _make_params():
+    torch.manual_seed(0)
+    big = torch.nn.Parameter(torch.randn(40, 32))
+    odd = torch.nn.Parameter(torch.randn(41, 31))       # 1271 elements: not a multiple of 8 * world
+    small = torch.nn.Parameter(torch.randn(5))
+    fused = torch.randn(48, 16)
+    # registered in the order (fb, fa): adjacency must be found by address, not by order
+    fa, fb = torch.nn.Parameter(torch.empty(0)), torch.nn.Parameter(torch.empty(0))
+    fa.data, fb.data = fused[:16], fused[16:]
+    unused = torch.nn.Parameter(torch.randn(9, 7))      # never receives a gradient
+    lonely = torch.nn.Parameter(torch.randn(600))       # own bucket, never receives a gradient
+    return big, odd, small, fa, fb, unused, lonely
+
+
+def _loss(ps, rank, micro=0):
+    big, odd, small, fa, fb, unused, lonely = ps
+    scale = torch.arange(1280.).view(40, 32) / 1280
+    m = micro + 1
+    return (FusedFn.apply(fa, fb, float(rank + 1) * m) + (big * scale * (rank + 1) * m).sum()
+            + (odd * (rank + 3)).sum() * m + (small * (2 * rank + 1)).sum() * m)
+
+
+def _expected_grads(world, micros):
+    """rank-mean gradients summed over the micro-batches"""
+    mr = sum(r + 1 for r in range(world)) / world
+    mo = sum(r + 3 for r in range(world)) / world
+    ms = sum(2 * r + 1 for r in range(world)) / world
+    mm = sum(m + 1 for m in range(micros))
+    scale = torch.arange(1280.).view(40, 32) / 1280
+    fscale = torch.cat([torch.ones(16, 16), 2 * torch.ones(32, 16)]) * (torch.arange(768.).view(48, 16) / 768 + 1)
+    return dict(big=mr * mm * scale, odd=torch.full((41, 31), mo * mm), small=torch.full((5,), ms * mm),
+                fused=mr * mm * fscale)
+
+
+def _worker(rank, world, port, q, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from macaw_llm_amd.bucketed import BucketedStep
+        ps = _make_params()
+        big, odd, small, fa, fb, unused, lonely = ps
+        ref = dict(big=big.detach().clone(), odd=odd.detach().clone(), small=small.detach().clone(),
+                   fused=torch.cat([fa.detach(), fb.detach()]).clone(), unused=unused.detach().clone(),
+                   lonely=lonely.detach().clone())
+        micros = 2 if mode == "accumulate" else 1
+        clip = 3.0 if mode == "clip" else None
+        opt = ShardSGD()
+        rt = BucketedStep([big, odd, small, fb, fa, unused, lonely], opt, bucket_bytes=6000,
+                          accumulate_steps=micros, max_grad_norm=clip)
+        ok = len(rt.buckets) >= 3
+        # fused run kept gap-free and in address order inside its bucket
+        ok = ok and fb.data.data_ptr() == fa.data.data_ptr() + fa.numel() * 4
+        for b in rt.buckets:
+            ok = ok and b.n % (8 * world) == 0
+        eg = _expected_grads(world, micros)
+        for it in range(2):
+            for m in range(micros):
+                rt.begin()
+                _loss(ps, rank, m).backward()
+                rt.finish()
+            sc = 1.0
+            if clip is not None:
+                nrm = math.sqrt(sum(float((g ** 2).sum()) for g in eg.values()))
+                sc = min(1.0, clip / (nrm + 1e-6))
+                ok = ok and abs(float(rt.grad_norm) - nrm) <= 1e-4 * nrm
+            for k in ("big", "odd", "small", "fused"):
+                ref[k] = ref[k] - 0.5 * sc * eg[k]
+            got = dict(big=big.data, odd=odd.data, small=small.data, fused=torch.cat([fa.data, fb.data]))
+            for k in got:
+                if not torch.allclose(got[k], ref[k], atol=1e-5, rtol=1e-5):
+                    ok = False
+                    print("DEBUG", mode, world, rank, it, k, (got[k] - ref[k]).abs().max().item(), flush=True)
+            # parameters without gradient: untouched (zero gradient in a used bucket; unused bucket skipped)
+            ok = ok and torch.equal(unused.data, ref["unused"]) and torch.equal(lonely.data, ref["lonely"])
+        ok = ok and opt.step_count == 2
+        # replicas identical (the all-gather really distributed the other ranks' slices)
+        flat = torch.cat([b.w for b in rt.buckets])
+        others = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(others, flat)
+        ok = ok and all(torch.equal(o, others[0]) for o in others)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["plain", "accumulate", "clip"])
+@pytest.mark.parametrize("world", [2, 8])
+def test_bucketed_step_gloo(world, mode):
+    if world == 8 and mode != "plain" and (os.cpu_count() or 1) < 4:
+        pytest.skip("too few cores for 8 ranks x 3 modes")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+def test_single_process_matches_plain_sgd_and_schedule():
+    from macaw_llm_amd.bucketed import BucketedStep, cosine_with_warmup
+    ps = _make_params()
+    big, odd, small, fa, fb, unused, lonely = ps
+    w0 = big.detach().clone()
+    opt = ShardSGD()
+    rt = BucketedStep(list(ps), opt, bucket_bytes=6000)
+    assert not rt.collective
+    rt.begin()
+    _loss(ps, 0).backward()
+    rt.finish()
+    scale = torch.arange(1280.).view(40, 32) / 1280
+    assert torch.allclose(big.data, w0 - 0.5 * scale)
+    assert big.grad is not None and torch.allclose(big.grad, scale)     # p.grad views the bucket
+    # HF cosine schedule with 3 % warm-up (train.sh)
+    import transformers
+    lin = torch.nn.Linear(2, 2)
+    o = torch.optim.SGD(lin.parameters(), lr=3e-5)
+    sch = transformers.get_cosine_schedule_with_warmup(o, num_warmup_steps=math.ceil(0.03 * 200), num_training_steps=200)
+    for step in range(200):
+        assert abs(sch.get_last_lr()[0] - cosine_with_warmup(step, 200, 0.03, 3e-5)) < 1e-12
+        o.step()
+        sch.step()
+    rt.set_lr(1e-4)
+    assert opt.lr == 1e-4
