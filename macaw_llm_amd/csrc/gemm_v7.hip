@@ -346,6 +346,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v7_kernel(GemmArgs g) {
     }                                                                                             \
     const bool rd_ = !(VAR & 16) || T == 0;                                                       \
     /* ---- phase 0: (A_lo, B_lo) ---- */                                                         \
+    if constexpr ((VAR & 2048) != 0) { if (B1NEXT) dma_b(B_BASE7 + (bslot ^ 1) * A_SLOT, 1, kB1); __builtin_amdgcn_sched_barrier(0); } \
     if (rd_) {                                                                                    \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) fbl_[ks_] = V7_FRAG(B_RED, bad_, 0, ks_); \
     __builtin_amdgcn_sched_barrier(0);                                                            \
@@ -354,26 +355,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v7_kernel(GemmArgs g) {
       fa_[1][ks_] = V7_FRAG(A_RED, aad_, 1, ks_);                                                 \
     }                                                                                             \
     }                                                                                             \
-    if constexpr (!(VAR & 3)) { if (B1NEXT) dma_b(B_BASE7 + (bslot ^ 1) * A_SLOT, 1, kB1); }      \
+    if constexpr (!(VAR & (3 | 2048))) { if (B1NEXT) dma_b(B_BASE7 + (bslot ^ 1) * A_SLOT, 1, kB1); } \
     V7_BAR();                                                                                     \
     V7_MMA(0, 0, fbl_, if (B1NEXT) dma_b(B_BASE7 + (bslot ^ 1) * A_SLOT, 1, kB1));                \
     if constexpr (!(VAR & 96)) V7_BAR();                                                          \
     /* ---- phase 1: (A_lo, B_hi) ---- */                                                         \
+    if constexpr ((VAR & 2048) != 0) { if (FULL) dma_a(a2_ * A_SLOT, 0, kA2); __builtin_amdgcn_sched_barrier(0); } \
     if (rd_) {                                                                                    \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) fbh_[ks_] = V7_FRAG(B_RED, bad_, 1, ks_); \
     }                                                                                             \
-    if constexpr (!(VAR & 3)) { if (FULL) dma_a(a2_ * A_SLOT, 0, kA2); }                          \
+    if constexpr (!(VAR & (3 | 2048))) { if (FULL) dma_a(a2_ * A_SLOT, 0, kA2); }                 \
     V7_BAR();                                                                                     \
     V7_MMA(0, 1, fbh_, if (FULL) dma_a(a2_ * A_SLOT, 0, kA2));                                    \
     if constexpr (!(VAR & 96)) V7_BAR();                                                          \
     /* ---- phase 2: (A_hi, B_hi) ---- */                                                         \
+    if constexpr ((VAR & 2048) != 0) { if (FULL) dma_a(a2_ * A_SLOT, 1, kA2); __builtin_amdgcn_sched_barrier(0); } \
     if (rd_) {                                                                                    \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                         \
       fa_[0][ks_] = V7_FRAG(A_RED, aad_, 2, ks_);                                                 \
       fa_[1][ks_] = V7_FRAG(A_RED, aad_, 3, ks_);                                                 \
     }                                                                                             \
     }                                                                                             \
-    if constexpr (!(VAR & 3)) { if (FULL) dma_a(a2_ * A_SLOT, 1, kA2); }                          \
+    if constexpr (!(VAR & (3 | 2048))) { if (FULL) dma_a(a2_ * A_SLOT, 1, kA2); }                 \
     V7_BAR();                                                                                     \
     V7_MMA(2, 1, fbh_, if (FULL) dma_a(a2_ * A_SLOT, 1, kA2));                                    \
     if constexpr (!(VAR & 96)) V7_BAR();                                                          \
@@ -467,6 +470,7 @@ int launch_v7(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t 
       case 16: return launch<false, false, 16>(g, grid, st);
       case 17: return launch<false, false, 17>(g, grid, st);
       case 6: return launch<false, false, 6>(g, grid, st);
+      case 2048: return launch<false, false, 2048>(g, grid, st);
       case 512: return launch<false, false, 512>(g, grid, st);
       case 256: return launch<false, false, 256>(g, grid, st);
       case 128: return launch<false, false, 128>(g, grid, st);

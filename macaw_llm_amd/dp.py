@@ -25,6 +25,9 @@ class GradSync:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
+        # RCCL reduces with AVG; gloo only has SUM (also for CUDA tensors staged through the host):
+        # the choice follows the BACKEND, not where the tensor lives
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.small_threshold = small_threshold
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self._handles = []
@@ -44,7 +47,7 @@ class GradSync:
         self._launch(p.grad)
 
     def _launch(self, t: torch.Tensor):
-        op = dist.ReduceOp.AVG if (self.average and t.is_cuda) else dist.ReduceOp.SUM
+        op = dist.ReduceOp.AVG if (self.average and self._avg) else dist.ReduceOp.SUM
         h = dist.all_reduce(t, op=op, group=self.group, async_op=True)
         self._handles.append((h, t, op))
 

@@ -15,6 +15,23 @@ class FusedAdamW:
         self.step_count = 0
         self.state = {}
 
+    @property
+    def param_groups(self):
+        """torch.optim-style view for schedulers / loggers that read or set `lr`:
+        `opt.param_groups[0]["lr"] = x` works (one group; the kernels read self.lr per launch)"""
+        outer = self
+
+        class _Group(dict):
+            def __setitem__(self, k, v):
+                if k == "lr":
+                    outer.lr = float(v)
+                elif k == "weight_decay":
+                    outer.weight_decay = float(v)
+                super().__setitem__(k, v)
+
+        return [_Group(params=self.params, lr=self.lr, betas=self.betas, eps=self.eps,
+                       weight_decay=self.weight_decay)]
+
     def _state(self, p):
         st = self.state.get(p)
         if st is None:
@@ -40,7 +57,22 @@ class FusedAdamW:
         b1, b2 = self.betas
         master, m, v = self._state(p)
         g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-        ops.adamw_(p.data, master, m, v, g, self.lr, b1, b2, self.eps, self.weight_decay,
+        w = p.data
+        if not w.is_contiguous():
+            raise ValueError("FusedAdamW: parameter storage must be contiguous (a strided view would be "
+                             "updated at the wrong elements)")
+        if (w.data_ptr() | g.data_ptr()) & 15:
+            # mk_adamw moves 16-byte vectors: an odd-offset slice of a fused buffer is updated through
+            # an aligned staging copy (rare: tiny ragged tensors only)
+            wa = torch.empty_like(w)
+            ops.copy2d(w, wa, 1, w.numel(), w.numel(), w.numel())
+            ga = torch.empty_like(g)
+            ops.copy2d(g, ga, 1, g.numel(), g.numel(), g.numel())
+            ops.adamw_(wa, master, m, v, ga, self.lr, b1, b2, self.eps, self.weight_decay,
+                       self.step_count, grad_scale)
+            ops.copy2d(wa, w, 1, w.numel(), w.numel(), w.numel())
+            return
+        ops.adamw_(w, master, m, v, g, self.lr, b1, b2, self.eps, self.weight_decay,
                    self.step_count, grad_scale)
 
     # ---- multi-tensor form ------------------------------------------------------------------

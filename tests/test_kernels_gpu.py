@@ -606,3 +606,33 @@ def test_adamw_multi_tensor_is_bit_identical_to_per_tensor(dev):
         for p, q in zip(pa, pb):
             assert torch.equal(p.data, q.data), (step, tuple(p.shape))
             assert torch.equal(oa.state[p][1], ob.state[q][1]) and torch.equal(oa.state[p][2], ob.state[q][2])
+
+
+def test_adamw_unaligned_slice_and_param_groups(dev):
+    """a parameter that is an odd-offset slice of a fused buffer (not 16-byte aligned)
+    used to hit MK_ERR_UNSUPPORTED in the 'fallback'; it now goes through an aligned staging copy
+    and must equal the aligned update bit for bit.  A strided view is rejected loudly."""
+    from macaw_llm_amd.optim import FusedAdamW
+    g = torch.Generator().manual_seed(21)
+    vals, grads = _rand((1003,), torch.bfloat16, g), _rand((1003,), torch.bfloat16, g)
+    buf = torch.zeros(1100, dtype=torch.bfloat16, device=dev)
+    pa = torch.nn.Parameter(torch.empty(0, device=dev))
+    pa.data = buf[3:1006]                      # byte offset 6: unaligned
+    pa.data.copy_(vals.to(dev))
+    pb = torch.nn.Parameter(vals.to(dev).clone())
+    oa, ob = FusedAdamW([pa], lr=1e-2, weight_decay=0.1), FusedAdamW([pb], lr=1e-2, weight_decay=0.1)
+    for _ in range(3):
+        gbuf = torch.zeros(1100, dtype=torch.bfloat16, device=dev)
+        gbuf[5:1008] = grads.to(dev)
+        pa.grad, pb.grad = gbuf[5:1008], grads.to(dev).clone()
+        oa.step()
+        ob.step()
+    assert torch.equal(pa.data, pb.data)
+    assert buf[:3].abs().sum() == 0 and buf[1006:].abs().sum() == 0      # neighbours untouched
+    ob.param_groups[0]["lr"] = 5e-3
+    assert ob.lr == 5e-3
+    ps = torch.nn.Parameter(torch.empty(0, device=dev))
+    ps.data = torch.zeros(64, 8, dtype=torch.bfloat16, device=dev)[:, :4]
+    ps.grad = torch.zeros(64, 4, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(ValueError):
+        FusedAdamW([ps]).step()
