@@ -887,7 +887,7 @@ int pick_cfg(const mk_gemm_desc* d, int nbatch, bool v7_ok, int n_cus) {
   const double nk = (d->K + 63) / 64;
   const long T7 = (long)mk_cdiv(d->M, 256) * mk_cdiv(d->N, 256);
   const long full = T7 / n_cus, R = T7 % n_cus;
-  const double a7 = layout == 3 ? 1.68 : layout == 1 ? 1.58 : layout == 2 ? 1.62 : 1.54;
+  const double a7 = layout == 3 ? 1.63 : layout == 1 ? 1.53 : layout == 2 ? 1.57 : 1.49;
   const double tile7 = nk * a7 + 14.0, sub7 = nk * 0.48 + 7.0;
   double t7 = full * tile7;
   // (a partially filled round of whole tiles runs faster per K-tile: less L2 / power contention)
@@ -996,8 +996,6 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     if (fp8) cfg = 5;
     else if (env_cfg >= 0) cfg = env_cfg;
     else cfg = pick_cfg(d, nbatch, v7_ok, n_cus);
-    int v7_var = 0;   // cfg 20 + VAR: experimental v7 schedules (only in MK_V7_EXPERIMENTS builds)
-    if (cfg >= 20) { v7_var = cfg - 20; cfg = 11; }
     if (cfg == 11 && !v7_ok) cfg = 5;
     if (cfg != 0 && cfg != 5 && cfg != 7 && cfg != 11) cfg = 5;
     if (cfg >= 5 && !v2_ok) cfg = 0;
@@ -1026,7 +1024,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     g.kt_per_piece = 0;
     g.ws = nullptr;
     g.counters = nullptr;
-    g.ablate = v7_var;
+    g.ablate = 0;
     // resident workgroups per CU of the chosen kernel
     const int slots = n_cus * (t256 ? 1 : (cfg == 7 ? 4 : 2));
     static const bool no_streamk = getenv("MK_GEMM_NO_STREAMK") != nullptr;

@@ -8,21 +8,23 @@
 //
 //   * 8 waves = 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 fragments of v_mfma_f32_32x32x16_bf16
 //     (128 accumulator registers), one workgroup per CU, two waves per SIMD.
-//   * A K-tile is computed in FOUR PHASES BY OUTPUT QUADRANT (rows lo/hi x columns lo/hi of the
-//     wave tile, full K = 64 each), not by k-step:  (A_lo,B_lo) (A_lo,B_hi) (A_hi,B_hi)
-//     (A_hi,B_lo).  LDS reads per phase: 12 / 4 / 8 / 0 x 16 B per lane, 8 MFMAs each.  The B
-//     operand of a K-tile is therefore dead after phase 1 and A after phase 2, which is what
-//     lets the NEXT-BUT-ONE tile's data be requested while this tile is still being computed:
+//   * A K-tile is computed BY OUTPUT QUADRANT (rows lo/hi x columns lo/hi of the wave tile, full
+//     K = 64 each), not by k-step, in TWO PHASES of 16 MFMAs:  A: (A_lo,B_lo) (A_lo,B_hi)   B:
+//     (A_hi,B_hi) (A_hi,B_lo).  LDS reads per phase: 16 / 8 x 16 B per lane.  The B operand of a
+//     K-tile is therefore dead after phase A and A after the reads of phase B, which is what lets
+//     the NEXT-BUT-ONE tile's data be requested while this tile is still being computed:
 //   * LDS = ten 16-KiB half-tile slots (all 160 KiB): A has 3 tile slots, B has 2.  A half-tile
 //     is 128 rows x 64 k = sixteen 1-KiB `buffer_load_dwordx4 ... lds` pieces, two per wave.
-//     Exactly ONE half-tile is requested per phase, in the fixed stream
-//         phase 0: B1(T+1)   phase 1: A0(T+2)   phase 2: A1(T+2)   phase 3: B0(T+2)
-//     Every slot is rewritten >= 2 phases after its last ds_read, every request has >= 3 phases
-//     to land, and the only wait in the loop is ONE counted `s_waitcnt vmcnt(6)` per K-tile (in
-//     phase 3: everything older than the last three half-tiles has landed = tile T+1 complete);
-//     vmcnt never drains to 0 inside the loop and the barriers are raw `s_barrier`s, so the
-//     LDS-DMA queue stays full across them (cdna_hip_programming.md "8-phase template",
-//     T3+T4, and "Pipelining across barriers").
+//     Phase A requests both halves of A(T+2) (into the slot A(T-1) left in phase B(T-1)), phase B
+//     both halves of B(T+2) (into the slot B(T) left in phase A(T)).  Reads retire (lgkmcnt 0)
+//     before the barrier that closes the segment issuing them, so every slot is rewritten at least
+//     one full phase after its last read; every request has two phases (one K-tile) to land, and
+//     the only wait in the loop is ONE counted `s_waitcnt vmcnt(8)` per K-tile (phase B:
+//     everything older than A(T+2), B(T+2) has landed = tile T+1 complete); vmcnt never drains to
+//     0 inside the loop and the barriers are raw `s_barrier`s, so the LDS-DMA queue stays full
+//     across them (cdna_hip_programming.md "8-phase template", T3+T4, "Pipelining across
+//     barriers").  Four phases of 8 MFMAs (the template's granularity) measured 3 % slower: each
+//     barrier interval costs ~30 cycles on top of its 256 / 512 MFMA cycles.
 //   * The two M-halves of the workgroup (waves 0-3 / 4-7 = one wave of each per SIMD) run one
 //     barrier out of phase: while one half issues its ds_reads and LDS-DMA, the other half owns
 //     the matrix pipe (s_setprio around the MFMA cluster).
@@ -231,11 +233,7 @@ MK_DEV void v7_subtile(const GemmArgs& g, int sub) {
   wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0, smem);
 }
 
-// VAR: experiment bits (scripts/gemm_bench.cpp, cfg 20 + VAR; 0 = the shipped schedule):
-//   1 no LDS-DMA inside the loop (ablation)   2 LDS-DMA issued inside the MFMA cluster
-//   4 no s_setprio   8 no stagger between the two wave groups   16 no ds_reads after tile 0
-//   32 / 64: the barrier that ends an MFMA cluster is placed before its last 2 / 4 MFMAs
-template <bool A_RED, bool B_RED, int VAR = 0>
+template <bool A_RED, bool B_RED>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_v7_kernel(GemmArgs g) {
   constexpr int FM = 4, FN = 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -318,91 +316,66 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v7_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);         \
   } while (0)
 // 8 MFMAs: rows I0, I0+1 (fragments held in fa_) x column fragment J (held in FB)
-#define V7_MMA(I0, J, FB, INNER)                                                                  \
+#define V7_MMA(I0, J, FB)                                                                         \
   do {                                                                                            \
-    if constexpr (!(VAR & 4)) __builtin_amdgcn_s_setprio(1);                                      \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                         \
-      if constexpr (!(VAR & 128)) {                                                               \
       acc[I0][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks_], fa_[0][ks_], acc[I0][J], 0, 0, 0); \
       acc[I0 + 1][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks_], fa_[1][ks_], acc[I0 + 1][J], 0, 0, 0); \
-      } else { asm volatile("" :: "v"(FB[ks_]), "v"(fa_[0][ks_]), "v"(fa_[1][ks_])); }            \
-      if constexpr ((VAR & 2) != 0) { if (ks_ == 0) { INNER; } }                                  \
-      if constexpr ((VAR & 32) != 0) { if (ks_ == 2) V7_BAR(); }                                  \
-      if constexpr ((VAR & 64) != 0) { if (ks_ == 1) V7_BAR(); }                                  \
     }                                                                                             \
-    if constexpr (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);                                      \
     /* register-only MFMAs are otherwise sunk / hoisted across the barriers (s5.7 item 3) */      \
     asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I0 + 1][J]));                                    \
   } while (0)
-// One K-tile.  FULL: tile T+2 exists (steady state); B1NEXT: tile T+1 exists (wave-uniform).
-#define V7_TILE(FULL, B1NEXT)                                                                     \
+// One K-tile.  FULL: tile T+2 exists (steady state); NEXT: tile T+1 exists (wave-uniform).
+#define V7_TILE(FULL, NEXT)                                                                      \
   do {                                                                                            \
     bf16x8 fa_[2][4], fbl_[4], fbh_[4];                                                           \
     int aad_[4], bad_[4];                                                                         \
-    const int a2_ = aslot >= 1 ? aslot - 1 : 2;              /* (aslot + 2) % 3 */               \
+    const int a2_ = aslot >= 1 ? aslot - 1 : 2;                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                            \
       aad_[i_] = aslot * A_SLOT + wr * HALF_BYTES + offA[i_];                                     \
       bad_[i_] = B_BASE7 + bslot * A_SLOT + (wc >> 1) * HALF_BYTES + offB[i_];                    \
     }                                                                                             \
-    const bool rd_ = !(VAR & 16) || T == 0;                                                       \
-    /* ---- phase 0: (A_lo, B_lo) ---- */                                                         \
-    if constexpr ((VAR & 2048) != 0) { if (B1NEXT) dma_b(B_BASE7 + (bslot ^ 1) * A_SLOT, 1, kB1); __builtin_amdgcn_sched_barrier(0); } \
-    if (rd_) {                                                                                    \
+    /* ---- phase A ---- */                                                                       \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) fbl_[ks_] = V7_FRAG(B_RED, bad_, 0, ks_); \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                         \
       fa_[0][ks_] = V7_FRAG(A_RED, aad_, 0, ks_);                                                 \
       fa_[1][ks_] = V7_FRAG(A_RED, aad_, 1, ks_);                                                 \
     }                                                                                             \
-    }                                                                                             \
-    if constexpr (!(VAR & (3 | 2048))) { if (B1NEXT) dma_b(B_BASE7 + (bslot ^ 1) * A_SLOT, 1, kB1); } \
-    V7_BAR();                                                                                     \
-    V7_MMA(0, 0, fbl_, if (B1NEXT) dma_b(B_BASE7 + (bslot ^ 1) * A_SLOT, 1, kB1));                \
-    if constexpr (!(VAR & 96)) V7_BAR();                                                          \
-    /* ---- phase 1: (A_lo, B_hi) ---- */                                                         \
-    if constexpr ((VAR & 2048) != 0) { if (FULL) dma_a(a2_ * A_SLOT, 0, kA2); __builtin_amdgcn_sched_barrier(0); } \
-    if (rd_) {                                                                                    \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) fbh_[ks_] = V7_FRAG(B_RED, bad_, 1, ks_); \
-    }                                                                                             \
-    if constexpr (!(VAR & (3 | 2048))) { if (FULL) dma_a(a2_ * A_SLOT, 0, kA2); }                 \
+    if (FULL) { dma_a(a2_ * A_SLOT, 0, kA2); dma_a(a2_ * A_SLOT, 1, kA2); }                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
     V7_BAR();                                                                                     \
-    V7_MMA(0, 1, fbh_, if (FULL) dma_a(a2_ * A_SLOT, 0, kA2));                                    \
-    if constexpr (!(VAR & 96)) V7_BAR();                                                          \
-    /* ---- phase 2: (A_hi, B_hi) ---- */                                                         \
-    if constexpr ((VAR & 2048) != 0) { if (FULL) dma_a(a2_ * A_SLOT, 1, kA2); __builtin_amdgcn_sched_barrier(0); } \
-    if (rd_) {                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                \
+    V7_MMA(0, 0, fbl_);                                                                           \
+    V7_MMA(0, 1, fbh_);                                                                           \
+    __builtin_amdgcn_s_setprio(0);                                                                \
+    V7_BAR();                                                                                     \
+    /* ---- phase B ---- */                                                                       \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                         \
       fa_[0][ks_] = V7_FRAG(A_RED, aad_, 2, ks_);                                                 \
       fa_[1][ks_] = V7_FRAG(A_RED, aad_, 3, ks_);                                                 \
     }                                                                                             \
-    }                                                                                             \
-    if constexpr (!(VAR & (3 | 2048))) { if (FULL) dma_a(a2_ * A_SLOT, 1, kA2); }                 \
-    V7_BAR();                                                                                     \
-    V7_MMA(2, 1, fbh_, if (FULL) dma_a(a2_ * A_SLOT, 1, kA2));                                    \
-    if constexpr (!(VAR & 96)) V7_BAR();                                                          \
-    /* ---- phase 3: (A_hi, B_lo); the tile's only wait ---- */                                   \
-    if constexpr (!(VAR & 1)) {                                                                   \
-    if constexpr ((VAR & 256) != 0) {                                                             \
-      if (FULL) dma_b(B_BASE7 + bslot * A_SLOT, 0, kB2);                                          \
-    } else if (FULL) {                                                                                   \
-      if constexpr (!(VAR & 2)) dma_b(B_BASE7 + bslot * A_SLOT, 0, kB2);                          \
-      if constexpr (!(VAR & 2)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                  \
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                       \
-    } else if (B1NEXT) {                                                                          \
+    if (FULL) {                                                                                   \
+      dma_b(B_BASE7 + bslot * A_SLOT, 0, kB2); dma_b(B_BASE7 + bslot * A_SLOT, 1, kB2);           \
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                            \
+    } else if (NEXT) {                                                                            \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
     }                                                                                             \
-    }                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
     V7_BAR();                                                                                     \
     asm volatile("" : "+v"(fbl_[0]), "+v"(fbl_[1]), "+v"(fbl_[2]), "+v"(fbl_[3]));                \
-    V7_MMA(2, 0, fbl_, if (FULL) dma_b(B_BASE7 + bslot * A_SLOT, 0, kB2));                        \
-    if constexpr (!(VAR & 96)) V7_BAR();                                                          \
+    __builtin_amdgcn_s_setprio(1);                                                                \
+    V7_MMA(2, 1, fbh_);                                                                           \
+    V7_MMA(2, 0, fbl_);                                                                           \
+    __builtin_amdgcn_s_setprio(0);                                                                \
+    V7_BAR();                                                                                     \
     aslot = aslot == 2 ? 0 : aslot + 1;                                                           \
     bslot ^= 1;                                                                                   \
-    kB1 += stepB; kA2 += stepA; kB2 += stepB;                                                     \
+    kA2 += stepA; kB2 += stepB;                                                                   \
   } while (0)
 
-  // ---- prologue: tile 0 complete, A(1) and B0(1) requested
-  int kB1 = (kt_begin + 1) * stepB, kA2 = (kt_begin + 2) * stepA, kB2 = (kt_begin + 2) * stepB;
+  // ---- prologue: tile 0 complete, tile 1 requested
+  int kA2 = (kt_begin + 2) * stepA, kB2 = (kt_begin + 2) * stepB;
   int aslot = 0, bslot = 0;
   if (nk > 0) {
     const int kA0 = kt_begin * stepA, kB0 = kt_begin * stepB;
@@ -414,45 +387,39 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v7_kernel(GemmArgs g) {
       dma_a(A_SLOT, 0, kA0 + stepA);
       dma_a(A_SLOT, 1, kA0 + stepA);
       dma_b(B_BASE7 + A_SLOT, 0, kB0 + stepB);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      dma_b(B_BASE7 + A_SLOT, 1, kB0 + stepB);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
   V7_BAR();                    // tile 0 landed for every wave's pieces
-  if (!(VAR & 8) && wr == 1) V7_BAR();   // stagger: the second M-half runs one barrier behind
+  if (wr == 1) V7_BAR();       // stagger: the second M-half runs one barrier behind
   if (nk > 0) {
 #pragma unroll 1
     for (int T = 0; T < nk; ++T) {
-      const bool full = T + 2 < nk, b1next = T + 1 < nk;
-      V7_TILE(full, b1next);
+      const bool full = T + 2 < nk, next = T + 1 < nk;
+      V7_TILE(full, next);
     }
   }
-  if (!(VAR & 8) && wr == 0) V7_BAR();   // re-align the two halves
+  if (wr == 0) V7_BAR();       // re-align the two halves
 #undef V7_TILE
 #undef V7_MMA
 #undef V7_BAR
 
-  if constexpr ((VAR & 512) != 0) {   // ablation: no epilogue (keep the accumulators live)
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(acc[i][j]));
-    return;
-  }
   wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0, smem);
 }
 
-template <bool A_RED, bool B_RED, int VAR = 0>
+template <bool A_RED, bool B_RED>
 int launch(const GemmArgs& g, dim3 grid, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v7_kernel<A_RED, B_RED, VAR>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v7_kernel<A_RED, B_RED>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS7) != hipSuccess)
       return MK_ERR_LAUNCH;
     attr_done = true;
   }
-  MK_LAUNCH((gemm_bf16_v7_kernel<A_RED, B_RED, VAR>), grid, dim3(512), LDS7, st, g);
+  MK_LAUNCH((gemm_bf16_v7_kernel<A_RED, B_RED>), grid, dim3(512), LDS7, st, g);
   return mk_check_launch();
 }
 
@@ -460,31 +427,6 @@ int launch(const GemmArgs& g, dim3 grid, hipStream_t st) {
 
 namespace mkg {
 int launch_v7(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st) {
-#ifdef MK_V7_EXPERIMENTS
-  if (!a_red && !b_red) {
-    switch (g.ablate) {
-      case 1: return launch<false, false, 1>(g, grid, st);
-      case 2: return launch<false, false, 2>(g, grid, st);
-      case 4: return launch<false, false, 4>(g, grid, st);
-      case 8: return launch<false, false, 8>(g, grid, st);
-      case 16: return launch<false, false, 16>(g, grid, st);
-      case 17: return launch<false, false, 17>(g, grid, st);
-      case 6: return launch<false, false, 6>(g, grid, st);
-      case 2048: return launch<false, false, 2048>(g, grid, st);
-      case 512: return launch<false, false, 512>(g, grid, st);
-      case 256: return launch<false, false, 256>(g, grid, st);
-      case 128: return launch<false, false, 128>(g, grid, st);
-      case 129: return launch<false, false, 129>(g, grid, st);
-      case 144: return launch<false, false, 144>(g, grid, st);
-      case 32: return launch<false, false, 32>(g, grid, st);
-      case 64: return launch<false, false, 64>(g, grid, st);
-      case 49: return launch<false, false, 49>(g, grid, st);
-      case 81: return launch<false, false, 81>(g, grid, st);
-      case 36: return launch<false, false, 36>(g, grid, st);
-      default: break;
-    }
-  }
-#endif
   if (!a_red && !b_red) return launch<false, false>(g, grid, st);
   if (!a_red && b_red) return launch<false, true>(g, grid, st);
   if (a_red && !b_red) return launch<true, false>(g, grid, st);
