@@ -320,6 +320,21 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const T* x, long ld, i
 }
 
 // ------------------------------------------------------------------ AdamW --
+// 4-element load / store in the parameter dtype (8 B for bf16, 16 B for fp32)
+MK_DEV void adam_load4(const bf16* p, float (&o)[4]) {
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (float)v[k];
+}
+MK_DEV void adam_load4(const float* p, float (&o)[4]) { VecIO<float>::load(p, o); }
+MK_DEV void adam_store4(bf16* p, const float (&o)[4]) {
+  bf16x4 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = (bf16)o[k];
+  *reinterpret_cast<bf16x4*>(p) = v;
+}
+MK_DEV void adam_store4(float* p, const float (&o)[4]) { VecIO<float>::store(p, o); }
+
 // 16-byte vector form: N = 8 (bf16) / 4 (fp32) parameters per thread and iteration
 // (28 B/param of HBM traffic: the kernel is a pure stream, cdna_hip_programming.md G13).
 template <typename T>
@@ -327,19 +342,21 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* param, float* master, flo
                                                     const T* grad, long n, float lr, float b1,
                                                     float b2, float eps, float wd, float bc1,
                                                     float bc2, float gscale) {
-  constexpr int N = VecIO<T>::N;
+  // 4 consecutive elements per thread and iteration: every wave instruction then covers
+  // CONTIGUOUS memory (fp32 arrays 16 B per lane = 1 KiB, bf16 arrays 8 B per lane = 512 B).  The
+  // former 8-element form read / wrote the fp32 state as two float4 32 bytes apart per lane, i.e.
+  // half-sector stores: 116 GB written per step for 99 GB of state (rocprofv3 WRITE_SIZE,
+  // calibrated on a memset) at 5.2 TB/s.
+  constexpr int N = 4;
   const long nch = n / N;
   const float ib1 = 1.f / bc1, ib2 = 1.f / bc2;
   for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long)gridDim.x * 256) {
     const long i0 = c * N;
     float g[N], w[N], mi[N], vi[N];
-    VecIO<T>::load(grad + i0, g);
-#pragma unroll
-    for (int k = 0; k < N; k += 4) {
-      VecIO<float>::load(master + i0 + k, *reinterpret_cast<float(*)[4]>(&w[k]));
-      VecIO<float>::load(m + i0 + k, *reinterpret_cast<float(*)[4]>(&mi[k]));
-      VecIO<float>::load(v + i0 + k, *reinterpret_cast<float(*)[4]>(&vi[k]));
-    }
+    adam_load4(grad + i0, g);
+    VecIO<float>::load(master + i0, w);
+    VecIO<float>::load(m + i0, mi);
+    VecIO<float>::load(v + i0, vi);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const float gk = g[k] * gscale;
@@ -350,13 +367,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* param, float* master, flo
       wk -= lr * (mi[k] * ib1) / (sqrtf(vi[k] * ib2) + eps);
       w[k] = wk;
     }
-#pragma unroll
-    for (int k = 0; k < N; k += 4) {
-      VecIO<float>::store(master + i0 + k, *reinterpret_cast<float(*)[4]>(&w[k]));
-      VecIO<float>::store(m + i0 + k, *reinterpret_cast<float(*)[4]>(&mi[k]));
-      VecIO<float>::store(v + i0 + k, *reinterpret_cast<float(*)[4]>(&vi[k]));
-    }
-    VecIO<T>::store(param + i0, w);
+    VecIO<float>::store(master + i0, w);
+    VecIO<float>::store(m + i0, mi);
+    VecIO<float>::store(v + i0, vi);
+    adam_store4(param + i0, w);
   }
   for (long i = nch * N + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float g = to_f32<T>(grad[i]) * gscale;
@@ -394,35 +408,54 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamItem* items,
   const long end = min(base + MK_ADAMW_CHUNK, it.n);
   T* param = reinterpret_cast<T*>(it.param);
   const T* grad = reinterpret_cast<const T*>(it.grad);
-  constexpr int N = VecIO<T>::N;
+  constexpr int N = 4;                      // see adamw_kernel: wave-contiguous accesses
   const float ib1 = 1.f / bc1, ib2 = 1.f / bc2;
   const long vec_end = base + (end - base) / N * N;
-  for (long i0 = base + (long)threadIdx.x * N; i0 < vec_end; i0 += 256L * N) {
-    float g[N], w[N], mi[N], vi[N];
-    VecIO<T>::load(grad + i0, g);
-#pragma unroll
-    for (int k = 0; k < N; k += 4) {
-      VecIO<float>::load(it.master + i0 + k, *reinterpret_cast<float(*)[4]>(&w[k]));
-      VecIO<float>::load(it.m + i0 + k, *reinterpret_cast<float(*)[4]>(&mi[k]));
-      VecIO<float>::load(it.v + i0 + k, *reinterpret_cast<float(*)[4]>(&vi[k]));
-    }
+  // two 4-element groups 256 * 4 elements apart per iteration: 8 independent 16-byte loads in
+  // flight per lane before the first use
+  for (long i0 = base + (long)threadIdx.x * N; i0 < vec_end; i0 += 512L * N) {
+    const long i1 = i0 + 256L * N;
+    const bool two = i1 < vec_end;             // (a chunk is 32768 elements: true except on a ragged tail)
+    const long j1 = two ? i1 : i0;
+    float g0[N], w0[N], m0[N], v0[N], g1[N], w1[N], m1[N], v1[N];
+    adam_load4(grad + i0, g0);
+    adam_load4(grad + j1, g1);
+    VecIO<float>::load(it.master + i0, w0);
+    VecIO<float>::load(it.master + j1, w1);
+    VecIO<float>::load(it.m + i0, m0);
+    VecIO<float>::load(it.m + j1, m1);
+    VecIO<float>::load(it.v + i0, v0);
+    VecIO<float>::load(it.v + j1, v1);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      const float gk = g[k] * gscale;
-      mi[k] = b1 * mi[k] + (1.f - b1) * gk;
-      vi[k] = b2 * vi[k] + (1.f - b2) * gk * gk;
-      float wk = w[k];
+      const float gk = g0[k] * gscale;
+      m0[k] = b1 * m0[k] + (1.f - b1) * gk;
+      v0[k] = b2 * v0[k] + (1.f - b2) * gk * gk;
+      float wk = w0[k];
       wk -= lr * wd * wk;
-      wk -= lr * (mi[k] * ib1) / (sqrtf(vi[k] * ib2) + eps);
-      w[k] = wk;
+      wk -= lr * (m0[k] * ib1) / (sqrtf(v0[k] * ib2) + eps);
+      w0[k] = wk;
     }
+    VecIO<float>::store(it.master + i0, w0);
+    VecIO<float>::store(it.m + i0, m0);
+    VecIO<float>::store(it.v + i0, v0);
+    adam_store4(param + i0, w0);
+    if (two) {
 #pragma unroll
-    for (int k = 0; k < N; k += 4) {
-      VecIO<float>::store(it.master + i0 + k, *reinterpret_cast<float(*)[4]>(&w[k]));
-      VecIO<float>::store(it.m + i0 + k, *reinterpret_cast<float(*)[4]>(&mi[k]));
-      VecIO<float>::store(it.v + i0 + k, *reinterpret_cast<float(*)[4]>(&vi[k]));
+      for (int k = 0; k < N; ++k) {
+        const float gk = g1[k] * gscale;
+        m1[k] = b1 * m1[k] + (1.f - b1) * gk;
+        v1[k] = b2 * v1[k] + (1.f - b2) * gk * gk;
+        float wk = w1[k];
+        wk -= lr * wd * wk;
+        wk -= lr * (m1[k] * ib1) / (sqrtf(v1[k] * ib2) + eps);
+        w1[k] = wk;
+      }
+      VecIO<float>::store(it.master + i1, w1);
+      VecIO<float>::store(it.m + i1, m1);
+      VecIO<float>::store(it.v + i1, v1);
+      adam_store4(param + i1, w1);
     }
-    VecIO<T>::store(param + i0, w);
   }
   for (long i = vec_end + threadIdx.x; i < end; i += 256) {
     const float g = to_f32<T>(grad[i]) * gscale;

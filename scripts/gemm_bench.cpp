@@ -10,6 +10,7 @@
 // cfg 3.  Data: A ~ N(0,1), B ~ 0.02 N(0,1) (weights) like the training step, never zeros
 // (cdna_hip_programming.md rule 25).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -158,13 +159,22 @@ int main(int argc, char** argv) {
     const long ldc = (s.N + 63) / 64 * 64;
     const long na = a_red ? lda * s.K : (long)s.M * lda, nb = b_red ? ldb * s.K : (long)s.N * ldb;
     const long nc = (long)s.M * ldc;
+    // GB_COLD=1: every timed launch reads a DIFFERENT copy of its operands (enough copies to exceed
+    // the 256 MB Infinity Cache several times), as inside a training step where weights and saved
+    // activations come from HBM; the default re-reads the same operands (cache-warm)
+    const bool cold = getenv("GB_COLD") != nullptr;
+    const int ncopy = cold ? (int)std::max<long>(2, (1536L << 20) / ((na + nb) * 2) + 1) : 1;
     bf16 *A, *B, *C;
-    CK(hipMalloc(&A, na * 2));
-    CK(hipMalloc(&B, nb * 2));
+    CK(hipMalloc(&A, na * 2 * ncopy));
+    CK(hipMalloc(&B, nb * 2 * ncopy));
     CK(hipMalloc(&C, nc * 2));
     // forward: A = activations, B = weights; grad-input: A = dy, B = W; grad-weight: both activations
     hipLaunchKernelGGL(fill_normal, dim3(2048), dim3(256), 0, st, A, na, 0x1234u + s.M, 1.0f);
     hipLaunchKernelGGL(fill_normal, dim3(2048), dim3(256), 0, st, B, nb, 0xbeefu + s.N, s.layout == 3 ? 1.0f : 0.02f);
+    for (int c = 1; c < ncopy; ++c) {
+      CK(hipMemcpyAsync(A + c * na, A, na * 2, hipMemcpyDeviceToDevice, st));
+      CK(hipMemcpyAsync(B + c * nb, B, nb * 2, hipMemcpyDeviceToDevice, st));
+    }
     if (kpad != s.K) {
       if (!a_red) CK(hipMemset2DAsync(A + s.K, lda * 2, 0, (kpad - s.K) * 2, s.M, st));
       if (!b_red) CK(hipMemset2DAsync(B + s.K, ldb * 2, 0, (kpad - s.K) * 2, s.N, st));
@@ -206,9 +216,15 @@ int main(int argc, char** argv) {
           CK(hipMemcpyAsync(&err[ci * 3], stats, 12, hipMemcpyDeviceToHost, st));
           CK(hipStreamSynchronize(st));
         }
-        for (int i = 0; i < 2; ++i) mk_gemm(&d, st);
+        auto launch = [&](int i) {
+          mk_gemm_desc dc = d;
+          dc.A = A + (long)(i % ncopy) * na;
+          dc.B = B + (long)(i % ncopy) * nb;
+          mk_gemm(&dc, st);
+        };
+        for (int i = 0; i < 2; ++i) launch(i + 7);
         CK(hipEventRecord(e0, st));
-        for (int i = 0; i < iters; ++i) mk_gemm(&d, st);
+        for (int i = 0; i < iters; ++i) launch(i);
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         float ms;

@@ -1,0 +1,72 @@
+#!/bin/bash
+# Produces the per-round profile artefacts (run on the GPU box from the repo root, through gpurun):
+#   gpurun_out/<R>_bench_cfg{2,3,4,5}.json            bench.py lines (cfg 3 with cpu_baseline)
+#   gpurun_out/<R>_cfgN_kernel_stats.csv, _last_step.txt   rocprofv3 --kernel-trace --stats of the same command
+#   gpurun_out/<R>_gemm_shapes_per_step.csv           per-shape GEMM / attention rates inside the step
+#   gpurun_out/<R>_step_traffic_pmc.csv               FETCH_SIZE / WRITE_SIZE per kernel of one cfg-3 step
+#   gpurun_out/<R>_gemm_pmc/                          PMC passes of the v7 / v2 kernels on one LLaMA shape
+#   gpurun_out/<R>_write_calibration.txt              WRITE_SIZE of a known 1 GiB memset (counter calibration)
+# usage: scripts/profile_round.sh r02 [what...]   what in: bench prof traffic gemmpmc rccl   (default: all)
+R=${1:-r02}; shift
+WHAT=${*:-bench prof traffic gemmpmc rccl}
+ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
+export TMPDIR=/tmp
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+
+if has bench; then
+  MACAW_GEMM_REPORT=$OUT/${R}_gemm_shapes_per_step.csv timeout 400 python bench.py --steps 10 --warmup 3 > $OUT/${R}_bench_cfg3.json 2> $OUT/${R}_bench_cfg3.err
+  for c in 2 4 5; do
+    timeout 500 python bench.py --config $c --steps 5 --warmup 2 > $OUT/${R}_bench_cfg$c.json 2> $OUT/${R}_bench_cfg$c.err
+  done
+fi
+if has prof; then
+  for c in 3 2 4 5; do
+    cd /tmp; rm -rf /tmp/prof_c$c
+    timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_c$c -o p --output-format csv -- python $ROOT/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${R}_prof_cfg$c.json 2> $OUT/${R}_prof_cfg$c.err
+    f=$(find /tmp/prof_c$c -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $OUT/${R}_cfg${c}_kernel_stats.csv
+    t=$(find /tmp/prof_c$c -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python3 $ROOT/scripts/trace_gaps.py "$t" > $OUT/${R}_cfg${c}_last_step.txt 2>&1
+    cd $ROOT
+  done
+fi
+if has traffic; then
+  cd /tmp
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_$ctr
+    timeout 600 rocprofv3 --pmc $ctr -d /tmp/pmc_$ctr -o p --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${R}_pmc_$ctr.err
+  done
+  fr=$(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
+  fw=$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
+  python3 $ROOT/scripts/pmc_step_traffic.py "$fr" "$fw" > $OUT/${R}_step_traffic_pmc.csv 2> $OUT/${R}_step_traffic.err
+  # counter calibration on a transfer of known size (MI355X_MICROARCH.md: WRITE_SIZE is uncalibrated)
+  rm -rf /tmp/pmc_cal
+  GB_WRITE_BW=1 GB_ITERS=1 GB_ROUNDS=1 timeout 120 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmc_cal -o p --output-format csv -- $ROOT/scripts/probe/_probe_gemm_bench $ROOT/scripts/gemm_shapes_pmc.txt > /dev/null 2>&1
+  fc=$(find /tmp/pmc_cal -name '*counter_collection.csv' | head -1)
+  python3 - "$fc" > $OUT/${R}_write_calibration.txt <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    if r["Counter_Name"] == "WRITE_SIZE":
+        agg[r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
+for k, v in agg.items():
+    print(f"{k}: launches {len(v)}, WRITE_SIZE values (KB) min {min(v):.0f} max {max(v):.0f}")
+PY
+  cd $ROOT
+fi
+if has gemmpmc; then
+  printf '4608 11008 4096 0 11\n4608 4096 11008 1 11\n11008 4096 4608 3 11\n' > /tmp/shapes_pmc.txt
+  cp /tmp/shapes_pmc.txt scripts/gemm_shapes_pmc3.txt
+  scripts/pmc_gemm.sh scripts/gemm_shapes_pmc3.txt gpurun_out/${R}_gemm_pmc > /dev/null 2>&1
+  # fabric traffic of the same three launches
+  cd /tmp
+  for ctr in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum; do
+    rm -rf /tmp/pmcg_$ctr
+    GB_ITERS=2 GB_ROUNDS=1 timeout 120 rocprofv3 --pmc $ctr -d /tmp/pmcg_$ctr -o p --output-format csv -- $ROOT/scripts/probe/_probe_gemm_bench $ROOT/scripts/gemm_shapes_pmc3.txt > /dev/null 2>&1
+    f=$(find /tmp/pmcg_$ctr -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp "$f" $OUT/${R}_gemm_pmc/traffic_$ctr.csv
+  done
+  cd $ROOT
+fi
+if has rccl; then
+  MACAW_FORCE_COLLECTIVES=1 timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${R}_bench_cfg3_1rank_rccl.json 2> $OUT/${R}_bench_rccl.err
+  MACAW_BUCKETED=1 timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${R}_bench_cfg3_bucketed_local.json 2>> $OUT/${R}_bench_rccl.err
+fi
+ls -la $OUT | grep "${R}_" | head -40
