@@ -34,7 +34,7 @@ extern "C" {
 #define MK_FP8 3 /* OCP e4m3fn bytes: mk_gemm operands / mk_fp8_quantize output only */
 
 /* library identification: returns MK_ABI_VERSION */
-#define MK_ABI_VERSION 3
+#define MK_ABI_VERSION 4
 int mk_abi_version(void);
 
 /* ------------------------------------------------------------------ GEMM --
@@ -262,6 +262,24 @@ int mk_cross_entropy_bwd(const void* logits, void* dlogits, const int64_t* label
 /* Greedy decoding (modeling.py:959, HF greedy_search): out[r] = index of the first maximum of
  * row r of x[rows][cols] (pitch ld). */
 int mk_argmax_rows(const void* x, int64_t ld, int32_t rows, int32_t cols, int64_t* out,
+                   int32_t dtype, void* stream);
+
+/* Decode step with the position in DEVICE memory (a fixed launch sequence per token: capturable in
+ * a hipGraph; modeling.py:190-195 appends with torch.cat and modeling.py:954-960 re-launches the
+ * eager step per token).
+ * mk_kv_append: cache[b][t][0:cols] = src[b][0:cols] for b < batch, t = clamp(*t_dev, 0, t_max - 1);
+ *   strides in elements: s_src / s_cache between samples, ld_cache between cache rows; 16-byte
+ *   aligned rows.
+ * mk_decode_attn: o[b][h][:] = softmax(scale * q[b][h] . k[b][0:T][h]) v[b][0:T][h] with
+ *   T = clamp(*t_dev + t_add, 1, t_max); one query row per (sample, head); q / o rows are
+ *   [H * hd] at batch strides q_bs / o_bs, keys and values [t_max][H * hd] at pitches k_ld / v_ld and
+ *   batch strides k_bs / v_bs.  bf16, hd in {16, 32, 64, 128}, t_max <= 15360 (scores in LDS). */
+int mk_kv_append(const void* src, void* cache, int32_t cols, int32_t batch, int64_t s_src,
+                 int64_t s_cache, int64_t ld_cache, const int32_t* t_dev, int32_t t_max,
+                 int32_t elem_size, void* stream);
+int mk_decode_attn(const void* q, const void* k, const void* v, void* o, const int32_t* t_dev,
+                   int32_t t_add, int32_t t_max, int32_t B, int32_t H, int32_t hd, int64_t q_bs,
+                   int64_t k_ld, int64_t k_bs, int64_t v_ld, int64_t v_bs, int64_t o_bs, float scale,
                    int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------ optimizer --

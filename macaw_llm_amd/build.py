@@ -20,7 +20,7 @@ OBJ = PKG / "csrc" / "_obj"
 LIB = PKG / "libmacaw_hip.so"
 ARCH = "gfx950"
 SOURCES = ["gemm.hip", "gemm_v7.hip", "norm.hip", "elementwise.hip", "softmax.hip", "attention.hip",
-           "preprocess.hip"]
+           "decode.hip", "preprocess.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", *os.environ.get("MK_EXTRA_FLAGS", "").split(),
          "-Wno-unused-result"]
 

@@ -665,6 +665,81 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs g) {
   }
 }
 
+// Same idea with 16 weight rows per workgroup (v_mfma_f32_16x16x32_bf16: 16 weight rows x 16 token
+// columns x 32 k): N / 16 workgroups instead of N / 32 -- the decode GEMMs stream 33 ... 262 MB
+// and last 6 ... 50 us, so what matters is that EVERY CU pulls from the first microsecond -- and a
+// two-stage register pipeline: the loads of trip i + 1 are in flight under the MFMAs of trip i
+// (U K-blocks of 64 per trip and wave: 2 U weight + 2 U token loads of 16 B per lane).
+template <int NW, int U>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs g) {
+  __shared__ float red[NW][4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = l & 15, kq = l >> 4;
+  const int n0 = blockIdx.x * 16;
+  const bf16* A = reinterpret_cast<const bf16*>(g.A);
+  const bf16* B = reinterpret_cast<const bf16*>(g.B);
+  const bf16* wp = B + (long)min(n0 + r16, g.N - 1) * g.ldb + 8 * kq;
+  const bf16* xp = A + (long)min(r16, g.M - 1) * g.lda + 8 * kq;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int nkb = g.K / 64;
+  // trip t of wave w covers K blocks w + NW * (t * U + u), u < U (neighbouring waves read
+  // neighbouring 128-byte lines of a row)
+  auto load = [&](bf16x8 (&wf)[2 * U], bf16x8 (&xf)[2 * U], int kb) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kk = min(kb + u * NW, nkb - 1);       // clamped: the MFMA of a clamped block is skipped
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        wf[2 * u + hh] = *reinterpret_cast<const bf16x8*>(wp + kk * 64 + 32 * hh);
+        xf[2 * u + hh] = *reinterpret_cast<const bf16x8*>(xp + kk * 64 + 32 * hh);
+      }
+    }
+  };
+  auto mma = [&](const bf16x8 (&wf)[2 * U], const bf16x8 (&xf)[2 * U], int kb) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (kb + u * NW < nkb) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * u], xf[2 * u], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * u + 1], xf[2 * u + 1], acc, 0, 0, 0);
+      }
+  };
+  bf16x8 wa[2 * U], xa[2 * U], wb[2 * U], xb[2 * U];
+  constexpr int STEP = NW * U;
+  int kb = w;
+  if (kb < nkb) load(wa, xa, kb);
+  while (kb < nkb) {
+    if (kb + STEP < nkb) load(wb, xb, kb + STEP);
+    mma(wa, xa, kb);
+    kb += STEP;
+    if (kb >= nkb) break;
+    if (kb + STEP < nkb) load(wa, xa, kb + STEP);
+    mma(wb, xb, kb);
+    kb += STEP;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[w][e][l] = acc[e];
+  __syncthreads();
+  // D[i = weight row][j = token]: lane holds j = l & 15, i = 4 * (l >> 4) + e
+  float alpha = g.alpha;
+  bf16* C = reinterpret_cast<bf16*>(g.C);
+  const bf16* Rp = reinterpret_cast<const bf16*>(g.R);
+  for (int t = threadIdx.x; t < 256; t += NW * 64) {
+    const int e = t >> 6, ll = t & 63;
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) v += red[ww][e][ll];   // fixed order: deterministic
+    const int m = ll & 15, n = n0 + 4 * (ll >> 4) + e;
+    if (m >= g.M || n >= g.N) continue;
+    v *= alpha;
+    if (g.bias_mode == 1) v += (float)reinterpret_cast<const bf16*>(g.bias)[n];
+    else if (g.bias_mode == 2) v += (float)reinterpret_cast<const bf16*>(g.bias)[m];
+    if (g.act) v = apply_act(v, g.act);
+    if (Rp) v += (float)Rp[(long)m * g.ldr + n];
+    bf16* cp = C + (long)m * g.ldc + n;
+    if (g.accumulate) v += (float)*cp;
+    *cp = (bf16)v;
+  }
+}
+
 // ------------------------------------------------------------------- f32 --
 // 64x64x16 tile, 4 waves (2x2) of 32x32, v_mfma_f32_16x16x4_f32 (exact f32).
 constexpr int FBM = 64, FBN = 64, FBK = 16, FPAD = 4;
@@ -955,8 +1030,17 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
   if (d->dtype == MK_BF16 && !fp8 && d->M <= 32 && d->M <= skinny_max && !d->a_red_major && !d->b_red_major && nbatch == 1 &&
       (d->K % 64) == 0 && (d->lda % 8) == 0 && (d->ldb % 8) == 0 && aligned16(d->A) && aligned16(d->B) &&
       !getenv("MK_GEMM_NO_SKINNY")) {
-    mkp::set_cfg(prof, 12);
-    MK_LAUNCH((gemm_skinny_kernel<8>), dim3(mk_cdiv(d->N, 32)), dim3(512), 0, st, g);
+    // cfg 12 = 32 weight rows per workgroup (8 waves), 17 / 18 = 16 rows per workgroup with 8 / 16
+    // waves splitting K (measured cold, scripts/gemm_shapes_decode.txt: 4.0 ... 5.7 TB/s against
+    // 2.1 ... 3.8; 16 waves where N / 16 workgroups alone would leave a CU with one short wave set)
+    int sk = d->M <= 16 ? ((d->N <= 16 * 256 && d->K <= 4096) ? 18 : 17) : 12;
+    if (g_force_cfg >= 12 && g_force_cfg <= 18 && (g_force_cfg == 12 || d->M <= 16)) sk = g_force_cfg;
+    mkp::set_cfg(prof, sk);
+    const dim3 g16(mk_cdiv(d->N, 16));
+    if (sk == 17) MK_LAUNCH((gemm_skinny16_kernel<8, 2>), g16, dim3(512), 0, st, g);
+    else if (sk == 18) MK_LAUNCH((gemm_skinny16_kernel<16, 2>), g16, dim3(1024), 0, st, g);
+    else if (sk == 13) MK_LAUNCH((gemm_skinny16_kernel<4, 4>), g16, dim3(256), 0, st, g);
+    else MK_LAUNCH((gemm_skinny_kernel<8>), dim3(mk_cdiv(d->N, 32)), dim3(512), 0, st, g);
     mkp::end(prof, st);
     return mk_check_launch();
   }

@@ -276,15 +276,22 @@ class LlamaLayerFn(torch.autograd.Function):
 
 
 def llama_layer_cached(x2, B, Sn, t0, kvc, Tmax, pos, cos, sin, n_heads, eps, wq, wk, wv, wo, wg, wu,
-                       wd, ln1, ln2, wqkv=None, wgu=None):
+                       wd, ln1, ln2, wqkv=None, wgu=None, t_dev=None):
     """No-grad decoder layer over `Sn` NEW positions per sample (rows of x2 are (b, s)) that
     start at position t0, with a preallocated KV cache kvc [B, Tmax, 2D] = [keys | values] per
     position (post-RoPE keys, modeling.py:183-195 semantics without the torch.cat per step).
     Sn = prompt length for the prefill (t0 = 0, causal), Sn = 1 for a decode step (attends to
     the t0 + 1 cached keys).  No attention mask (the reference's generate passes none,
     modeling.py:959 / SURVEY Q7).  With fused q|k|v storage a step is one GEMM, ONE RoPE launch
-    over the q and k heads and ONE strided copy of [k | v] into the cache."""
+    over the q and k heads and ONE strided copy of [k | v] into the cache.
+
+    t_dev (int32[1] on the device, Sn = 1 only): the position is read from device memory by the
+    cache append and the attention kernel (`pos` already is a device tensor) and t0 is ignored, so
+    the launch sequence does not depend on the step and can be replayed from a hipGraph."""
     M, D = x2.shape
+    dyn = t_dev is not None
+    if dyn and Sn != 1:
+        raise ValueError("llama_layer_cached: t_dev is for single-position decode steps")
     H, hd = n_heads, D // n_heads
     FF = wg.shape[0]
     _, y1, _ = ops.rmsnorm_fwd(x2, ln1, eps)
@@ -294,21 +301,31 @@ def llama_layer_cached(x2, B, Sn, t0, kvc, Tmax, pos, cos, sin, n_heads, eps, wq
         q = qkv[:, :D]
         ldq = 3 * D
         ops.rope_(qkv[:, :2 * D], cos, sin, pos, 2 * H, hd)
-        ops.copy2d(qkv, kvc, Sn, 2 * D, ldq, ldc, batch=B, s_src=Sn * ldq, s_dst=Tmax * ldc, src_off=D,
-                   dst_off=t0 * ldc)
+        if dyn:
+            ops.kv_append(qkv, kvc, 2 * D, B, ldq, Tmax * ldc, ldc, t_dev, Tmax, src_off=D)
+        else:
+            ops.copy2d(qkv, kvc, Sn, 2 * D, ldq, ldc, batch=B, s_src=Sn * ldq, s_dst=Tmax * ldc, src_off=D,
+                       dst_off=t0 * ldc)
     else:
         q, k, v = ops.linear_fwd(y1, wq), ops.linear_fwd(y1, wk), ops.linear_fwd(y1, wv)
         ldq = D
         ops.rope_(q, cos, sin, pos, H, hd)
         ops.rope_(k, cos, sin, pos, H, hd)
         # append the new keys / values to the cache rows [t0, t0 + Sn) of every sample
-        ops.copy2d(k, kvc, Sn, D, ldq, ldc, batch=B, s_src=Sn * ldq, s_dst=Tmax * ldc, dst_off=t0 * ldc)
-        ops.copy2d(v, kvc, Sn, D, ldq, ldc, batch=B, s_src=Sn * ldq, s_dst=Tmax * ldc, dst_off=t0 * ldc + D)
+        if dyn:
+            ops.kv_append(k, kvc, D, B, ldq, Tmax * ldc, ldc, t_dev, Tmax)
+            ops.kv_append(v, kvc, D, B, ldq, Tmax * ldc, ldc, t_dev, Tmax, dst_off=D)
+        else:
+            ops.copy2d(k, kvc, Sn, D, ldq, ldc, batch=B, s_src=Sn * ldq, s_dst=Tmax * ldc, dst_off=t0 * ldc)
+            ops.copy2d(v, kvc, Sn, D, ldq, ldc, batch=B, s_src=Sn * ldq, s_dst=Tmax * ldc, dst_off=t0 * ldc + D)
     kc, vc = kvc[:, :, :D], kvc[:, :, D:]
     T = t0 + Sn
     att = torch.empty((M, D), dtype=x2.dtype, device=x2.device)
     scale = 1.0 / math.sqrt(hd)
-    if flash_ok(x2.dtype, hd):
+    if dyn:
+        ops.decode_attn(q, kvc, kvc, att, t_dev, 1, Tmax, B, H, hd, ldq, ldc, Tmax * ldc, ldc, Tmax * ldc, D,
+                        scale, v_off=D)
+    elif flash_ok(x2.dtype, hd):
         ops.flash_attn_fwd(q, kc, vc, att, B, H, Sn, T, hd, ldq, Sn * ldq, ldc, Tmax * ldc, ldc, Tmax * ldc,
                            D, Sn * D, scale, causal=True)
     else:

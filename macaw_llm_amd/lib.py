@@ -19,7 +19,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libmacaw_hip.so"
 
 MK_F32, MK_BF16, MK_F16, MK_FP8 = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _ERR = {-1: "MK_ERR_BAD_ARG", -2: "MK_ERR_UNSUPPORTED", -3: "MK_ERR_LAUNCH"}
 
@@ -94,6 +94,9 @@ SIGNATURES = {
     "mk_cross_entropy": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp],
     "mk_cross_entropy_bwd": [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i64, _i32, _vp],
     "mk_argmax_rows": [_vp, _i64, _i32, _i32, _vp, _i32, _vp],
+    "mk_kv_append": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _i32, _vp],
+    "mk_decode_attn": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64,
+                       _i64, _f32, _i32, _vp],
     "mk_adamw": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _i32,
                  _vp],
     "mk_adamw_multi": [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _i32, _vp],

@@ -413,8 +413,60 @@ class LlamaForCausalLM(LlamaPreTrainedModel):
                                       hidden_states=None, attentions=None)
 
     @torch.no_grad()
+    def _generate_graph(self, run, select, last, emb_w, B, S0, max_new_tokens, eos, pad, dev):
+        """Decode loop with ONE hipGraph launch per token.  Everything a step needs lives in device
+        memory -- the position (int32 counter read by the RoPE, cache-append and attention kernels),
+        the last token ids, the per-sample finished flags and the output matrix -- so the ~330
+        kernel launches of a step are captured once (after one eager step that also serves as the
+        warm-up) and replayed; the host only looks at the finished flags every few tokens.  Same
+        kernels and arithmetic as the eager loop except the attention kernel (ops.decode_attn)."""
+        t_dev = torch.full((1,), S0, dtype=torch.int32, device=dev)      # position of the token being fed
+        pos = torch.full((B,), S0, dtype=torch.int32, device=dev)
+        tok = torch.zeros(B, dtype=torch.long, device=dev)
+        done = torch.zeros(B, dtype=torch.bool, device=dev)
+        col = torch.zeros((B, 1), dtype=torch.long, device=dev)
+        out_buf = torch.full((B, max_new_tokens), pad, dtype=torch.long, device=dev)
+        padv = torch.full((B,), pad, dtype=torch.long, device=dev)
+
+        def emit(h_last):
+            nxt = torch.where(done, padv, select(h_last))
+            out_buf.scatter_(1, col, nxt.view(B, 1))
+            done.logical_or_(nxt == eos)
+            col.add_(1)
+            tok.copy_(nxt)
+
+        def step():
+            h = run(ops.embedding_fwd(emb_w, tok), 1, 0, pos=pos, t_dev=t_dev)
+            emit(h)
+            t_dev.add_(1)
+            pos.add_(1)
+
+        emit(last)                       # token 0 (from the prefill)
+        emitted = 1
+        if not bool(done.all()):
+            step()                       # token 1: eager (kernel attributes, allocator pools, workspace)
+            emitted += 1
+        remaining = max_new_tokens - emitted
+        if remaining > 0 and not bool(done.all()):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            for i in range(remaining):
+                graph.replay()
+                emitted += 1
+                if (i & 7) == 7 and bool(done.all()):
+                    break
+            del graph
+        res = out_buf[:, :emitted]
+        # the eager loop stops right after the token at which every sample has finished
+        fin = ((res == eos).cumsum(1) > 0).all(0)
+        if bool(fin.any()):
+            res = res[:, : int(torch.nonzero(fin)[0]) + 1]
+        return res.clone()
+
+    @torch.no_grad()
     def generate(self, inputs_embeds=None, input_ids=None, max_new_tokens=128, eos_token_id=2,
-                 bos_token_id=1, pad_token_id=None, use_cache=True, **_):
+                 bos_token_id=1, pad_token_id=None, use_cache=True, decode_graph=True, **_):
         """Greedy decode — the only mode the reference uses (modeling.py:959:
         `llm.generate(inputs_embeds=…, max_new_tokens=128, eos_token_id=2, bos_token_id=1,
         pad_token_id=32006)`, no attention mask).  Prefill runs the prompt once and fills a
@@ -469,8 +521,9 @@ class LlamaForCausalLM(LlamaPreTrainedModel):
         cos, sin = rot.tables(Tmax, dtype, dev)
         kvc = [torch.empty((B, Tmax, 2 * D), dtype=dtype, device=dev) for _ in layers]   # [keys | values]
 
-        def run(x2, Sn, t0):
-            pos = (torch.arange(t0, t0 + Sn, dtype=torch.int32, device=dev)).repeat(B)
+        def run(x2, Sn, t0, pos=None, t_dev=None):
+            if pos is None:
+                pos = (torch.arange(t0, t0 + Sn, dtype=torch.int32, device=dev)).repeat(B)
             for i, lyr in enumerate(layers):
                 a, m = lyr.self_attn, lyr.mlp
                 x2 = eng.llama_layer_cached(
@@ -478,12 +531,16 @@ class LlamaForCausalLM(LlamaPreTrainedModel):
                     lyr.input_layernorm.variance_epsilon, a.q_proj.weight, a.k_proj.weight,
                     a.v_proj.weight, a.o_proj.weight, m.gate_proj.weight, m.up_proj.weight,
                     m.down_proj.weight, lyr.input_layernorm.weight,
-                    lyr.post_attention_layernorm.weight, *lyr.fused_weights())
+                    lyr.post_attention_layernorm.weight, *lyr.fused_weights(), t_dev=t_dev)
             return x2
 
         h = run(eng._c2(inputs_embeds, B * S0, D), S0, 0)                 # prefill
         last = torch.empty((B, D), dtype=dtype, device=dev)
         ops.copy2d(h, last, 1, D, D, D, batch=B, s_src=S0 * D, s_dst=D, src_off=(S0 - 1) * D)
+        hd = D // layers[0].self_attn.num_heads
+        if (decode_graph and max_new_tokens > 2 and ops.decode_attn_ok(dtype, hd, Tmax)
+                and not os.environ.get("MACAW_NO_DECODE_GRAPH")):
+            return self._generate_graph(run, select, last, emb_w, B, S0, max_new_tokens, eos_token_id, pad, dev)
         for t in range(max_new_tokens):
             nxt = torch.where(done, torch.full((B,), pad, dtype=torch.long, device=dev), select(last))
             out.append(nxt)

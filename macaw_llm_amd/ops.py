@@ -402,6 +402,31 @@ def copy2d(src, dst, rows, cols, ld_src, ld_dst, batch=1, s_src=0, s_dst=0, src_
     return dst
 
 
+def kv_append(src, cache, cols, batch, s_src, s_cache, ld_cache, t_dev, t_max, src_off=0, dst_off=0):
+    """cache[b, *t_dev, dst_off : dst_off + cols] = src[b, src_off : src_off + cols]; the row index is
+    read from the DEVICE int32 t_dev at execution time (graph-capturable decode step)"""
+    lib = _L.load()
+    es = src.element_size()
+    _L.check(lib.mk_kv_append(_p(src) + src_off * es, _p(cache) + dst_off * es, cols, batch, s_src, s_cache,
+                              ld_cache, _p(t_dev), t_max, es, _st()), "mk_kv_append")
+    return cache
+
+
+def decode_attn(q, k, v, out, t_dev, t_add, t_max, B, H, hd, q_bs, k_ld, k_bs, v_ld, v_bs, o_bs, scale,
+                k_off=0, v_off=0):
+    """one query row per (sample, head) against the first *t_dev + t_add cached keys (device int32)"""
+    lib = _L.load()
+    es = q.element_size()
+    _L.check(lib.mk_decode_attn(_p(q), _p(k) + k_off * es, _p(v) + v_off * es, _p(out), _p(t_dev), t_add,
+                                t_max, B, H, hd, q_bs, k_ld, k_bs, v_ld, v_bs, o_bs, scale, dt(q), _st()),
+             "mk_decode_attn")
+    return out
+
+
+def decode_attn_ok(dtype, hd, t_max):
+    return dtype == torch.bfloat16 and hd in (16, 32, 64, 128) and t_max * 4 <= 60 * 1024
+
+
 def embedding_fwd(table, ids, out=None):
     """out[t, :] = table[ids[t], :]; ids int64 1-D"""
     lib = _L.load()

@@ -552,7 +552,8 @@ def test_flash_attention_bwd(dev, hd, Lq, Lk, causal, masked):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 22016, 4096), (32, 4096, 11008), (5, 107, 128),
-                                   (2, 32007, 4096), (31, 250, 192)])
+                                   (2, 32007, 4096), (31, 250, 192), (16, 4096, 11008), (7, 4000, 1024),
+                                   (13, 520, 704)])
 def test_gemm_skinny_decode_rows(dev, M, N, K):
     """M <= 32 (one decode position per sample): the weight-streaming kernel (W rows as the MFMA M
     dimension, split-K across the waves of a workgroup) with every epilogue option, against fp32
@@ -636,3 +637,38 @@ def test_adamw_unaligned_slice_and_param_groups(dev):
     ps.grad = torch.zeros(64, 4, dtype=torch.bfloat16, device=dev)
     with pytest.raises(ValueError):
         FusedAdamW([ps]).step()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hd,H,B,T", [(128, 32, 1, 173), (128, 4, 3, 1), (64, 8, 2, 64), (32, 4, 2, 333), (16, 4, 3, 40)])
+def test_decode_attn_and_kv_append_with_device_position(hd, H, B, T):
+    """mk_kv_append / mk_decode_attn read the position from device memory: one query row per
+    (sample, head) against the first T cached keys, fp32 reference"""
+    from macaw_llm_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(hd + T)
+    D, Tmax = H * hd, T + 7
+    cache = torch.zeros((B, Tmax, 2 * D), dtype=torch.bfloat16, device=dev)
+    cache[:, : T - 1] = torch.randn((B, T - 1, 2 * D), device=dev).to(torch.bfloat16)
+    qkv = torch.randn((B, 3 * D), device=dev).to(torch.bfloat16)
+    t_dev = torch.tensor([T - 1], dtype=torch.int32, device=dev)
+    before = cache.clone()
+    ops.kv_append(qkv, cache, 2 * D, B, 3 * D, Tmax * 2 * D, 2 * D, t_dev, Tmax, src_off=D)
+    assert torch.equal(cache[:, T - 1], qkv[:, D:])
+    before[:, T - 1] = qkv[:, D:]
+    assert torch.equal(cache, before)                     # nothing else touched
+    out = torch.empty((B, D), dtype=torch.bfloat16, device=dev)
+    scale = 1.0 / hd ** 0.5
+    ops.decode_attn(qkv, cache, cache, out, t_dev, 1, Tmax, B, H, hd, 3 * D, 2 * D, Tmax * 2 * D, 2 * D,
+                    Tmax * 2 * D, D, scale, v_off=D)
+    q = qkv[:, :D].float().view(B, H, 1, hd)
+    k = cache[:, :T, :D].float().view(B, T, H, hd).permute(0, 2, 1, 3)
+    v = cache[:, :T, D:].float().view(B, T, H, hd).permute(0, 2, 1, 3)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).reshape(B, D)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
+    # the position really is read at execution time
+    t_dev.fill_(0)
+    ops.decode_attn(qkv, cache, cache, out, t_dev, 1, Tmax, B, H, hd, 3 * D, 2 * D, Tmax * 2 * D, 2 * D,
+                    Tmax * 2 * D, D, scale, v_off=D)
+    assert torch.allclose(out.float(), cache[:, 0, D:].float(), atol=1e-6)   # one key: output = its value

@@ -179,6 +179,35 @@ def test_generate_kv_cache_bf16_and_inference_flag(dev):
     assert gen.dim() == 2 and gen.shape[0] == emb.shape[0] and gen.shape[1] <= 128
 
 
+def test_generate_hipgraph_decode_matches_eager_loop(dev):
+    """the decode loop replayed from ONE captured graph per token (device-side position, token,
+    finished flags) must emit the ids of the eager per-kernel loop, including the early stop when
+    every sample has produced eos and pad ids for samples that finished earlier"""
+    fx = load_case("micro_all")
+    cfg = configs.get(fx["config_name"])
+    model = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=True).eval()
+    emb = fx["inputs_embeds"].to(dev).to(torch.bfloat16)
+    for eos in (2, -1):
+        g = model.llm.generate(inputs_embeds=emb, max_new_tokens=24, eos_token_id=eos, pad_token_id=106)
+        e = model.llm.generate(inputs_embeds=emb, max_new_tokens=24, eos_token_id=eos, pad_token_id=106,
+                               decode_graph=False)
+        assert g.dtype == torch.long and g.shape == e.shape, (g.shape, e.shape)
+        agree = (g == e).float().mean().item()
+        assert agree >= 0.9, agree      # different attention kernel: a bf16 near-tie may flip an argmax
+    # force an early stop: use the most frequent greedy token as eos
+    e = model.llm.generate(inputs_embeds=emb, max_new_tokens=24, eos_token_id=-1, pad_token_id=106, decode_graph=False)
+    eos = int(e[:, 2:].flatten().mode().values)
+    g = model.llm.generate(inputs_embeds=emb, max_new_tokens=24, eos_token_id=eos, pad_token_id=106)
+    e = model.llm.generate(inputs_embeds=emb, max_new_tokens=24, eos_token_id=eos, pad_token_id=106,
+                           decode_graph=False)
+    assert g.shape == e.shape and (g == e).float().mean().item() >= 0.9
+    # and in fp32 parameters (no fused decode attention: the graph path must step aside)
+    m32 = build_model(cfg, fx["state"], torch.float32, dev).eval()
+    ids = m32.llm.generate(inputs_embeds=fx["inputs_embeds"].to(dev), max_new_tokens=8, eos_token_id=2,
+                           bos_token_id=1, pad_token_id=cfg["tags"]["pad"])
+    assert torch.equal(ids.cpu(), fx["generate_ids"])
+
+
 def test_reference_construction_path_runs_the_fused_kernels(dev):
     """run_clm_llms.py:478-497 builds the model as MM_LLMs(config) -> resize_token_embeddings ->
     freeze -> Trainer .to(device / dtype).  That path must hit the SAME launches as
