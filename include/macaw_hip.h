@@ -274,6 +274,33 @@ int mk_argmax_rows(const void* x, int64_t ld, int32_t rows, int32_t cols, int64_
  *   T = clamp(*t_dev + t_add, 1, t_max); one query row per (sample, head); q / o rows are
  *   [H * hd] at batch strides q_bs / o_bs, keys and values [t_max][H * hd] at pitches k_ld / v_ld and
  *   batch strides k_bs / v_bs.  bf16, hd in {16, 32, 64, 128}, t_max <= 15360 (scores in LDS). */
+/* mk_decode_linear: y[M][N] = prologue(x) W^T (+ residual) for M <= 16 token rows (bf16, K % 64 == 0,
+ *   16-byte aligned rows), the weight-streaming kernel of mk_gemm's M <= 16 path with the operation
+ *   that precedes the linear folded in: prologue 0 = none (x [M][K]); 1 = RMSNorm (x [M][K], norm_w
+ *   [K], eps: y = (norm_w * rnd(x * rstd)) W^T, modeling.py:100-105); 2 = SwiGLU (x [M][2K] =
+ *   [gate | up]: (rnd(silu(gate)) * up) W^T, modeling.py:140).  With a prologue the prepared token rows
+ *   are staged in LDS: M * (K + 8) * 2 bytes <= 40 KiB, else MK_ERR_UNSUPPORTED (use the separate
+ *   kernels). */
+int mk_decode_linear(const void* x, int64_t ldx, const void* W, int64_t ldw, void* y, int64_t ldy,
+                     const void* residual, int64_t ldr, int32_t M, int32_t N, int32_t K,
+                     int32_t prologue, const void* norm_w, float eps, int32_t dtype, void* stream);
+/* mk_decode_emit: greedy selection + bookkeeping of one decode step (modeling.py:959, HF greedy_search):
+ *   for every sample b: nxt = done[b] ? pad : first argmax of logits[b][0:V]; out[b][state[1]] = nxt;
+ *   done[b] |= (nxt == eos); tok[b] = nxt.  Then, once: state[0] += 1 (the position the other decode
+ *   kernels read), state[1] += 1 (output column); state[2] is an arrival counter that must be zero
+ *   before the first launch and is left zero.  done: one byte per sample. */
+int mk_decode_emit(const void* logits, int64_t ld, int32_t V, int32_t B, int64_t pad, int64_t eos,
+                   int64_t* tok, void* done, int64_t* out, int64_t out_ld, int32_t* state, int32_t dtype,
+                   void* stream);
+/* mk_decode_step_attn: the attention block of one decode step in one launch: p = clamp(*t_dev, 0,
+ *   t_max - 1); q and k_new (rows [H * hd] at batch stride in_bs) are rotated with rows p of the
+ *   [positions][hd] cos / sin tables (modeling.py:76-91, rope rounding points of mk_rope); the rotated
+ *   key and v_new go to row p of the caches; o = attention of the rotated query over keys 0 ... p. */
+int mk_decode_step_attn(const void* q, const void* k_new, const void* v_new, int64_t in_bs,
+                        const void* cos_t, const void* sin_t, void* k_cache, void* v_cache,
+                        int64_t kv_ld, int64_t kv_bs, void* o, int64_t o_bs, const int32_t* t_dev,
+                        int32_t t_max, int32_t B, int32_t H, int32_t hd, float scale, int32_t dtype,
+                        void* stream);
 int mk_kv_append(const void* src, void* cache, int32_t cols, int32_t batch, int64_t s_src,
                  int64_t s_cache, int64_t ld_cache, const int32_t* t_dev, int32_t t_max,
                  int32_t elem_size, void* stream);

@@ -5,6 +5,7 @@
 //
 //   mk_kv_append    cache[b][*t_dev][0:cols] = src[b][0:cols]   (post-RoPE keys | values of the new token)
 //   mk_decode_attn  one query row per (sample, head) against the first *t_dev + t_add cached keys
+//   mk_decode_step_attn  RoPE(q, k_new) + append(k_new, v_new) + that attention in one launch
 //
 // The fused training / prefill attention (attention.hip) works on 128-row query tiles: at Lq = 1
 // it would spend 127 of 128 MFMA rows on padding and, more to the point here, takes its key count
@@ -121,7 +122,251 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeArgs a) {
   }
 }
 
+// The whole attention block of a decode step in ONE launch: RoPE of the new query and key
+// (modeling.py:76-91, same rounding points as rope_kernel: each product and the sum rounded to
+// bf16), append of the rotated key and the value to cache row p = *t_dev, and the attention of the
+// query over keys 0 ... p (the new key / value straight from registers).  NWV waves per (head, sample).
+struct DecodeStepArgs {
+  const bf16* q; const bf16* kn; const bf16* vn; long in_bs;   // new rows [H * hd] per sample
+  const bf16* cos_t; const bf16* sin_t;                       // [positions][hd]
+  bf16* kc; bf16* vc; long kv_ld, kv_bs;                      // caches [t_max][H * hd] per sample
+  bf16* o; long o_bs;
+  const int32_t* t_dev;
+  int t_max;
+  float scale;
+};
+
+MK_DEV float rnd_bf16(float x) { return rnd<bf16>(x); }
+
+template <int HD, int NWV>
+__global__ __launch_bounds__(NWV * 64) void decode_step_attn_kernel(DecodeStepArgs a) {
+  constexpr int LPK = HD / 8, KPW = 64 / LPK, KPP = NWV * KPW;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sc = reinterpret_cast<float*>(smem_raw);
+  __shared__ float red[NWV][HD];
+  __shared__ float redw[2 * NWV];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = min(max(*a.t_dev, 0), a.t_max - 1);
+  const int T = p + 1;
+  const int sub = lane % LPK, grp = lane / LPK;
+  const int d0 = sub * 8;
+  const bool first = d0 < HD / 2;
+  const long in_off = (long)b * a.in_bs + (long)h * HD + d0;
+  float qf[8], kf[8];
+  bf16x8 vnew = *reinterpret_cast<const bf16x8*>(a.vn + in_off);
+  {
+    const bf16x8 qv = *reinterpret_cast<const bf16x8*>(a.q + in_off);
+    const bf16x8 kv = *reinterpret_cast<const bf16x8*>(a.kn + in_off);
+    const bf16x8 cv = *reinterpret_cast<const bf16x8*>(a.cos_t + (long)p * HD + d0);
+    const bf16x8 sv = *reinterpret_cast<const bf16x8*>(a.sin_t + (long)p * HD + d0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float cs = (float)cv[e], sn = (float)sv[e];
+      const float qo = (float)qv[e], ko = (float)kv[e];
+      const float qp = __shfl_xor(qo, LPK / 2, 64), kp = __shfl_xor(ko, LPK / 2, 64);
+      // first half: x cos - partner sin; second half: x cos + partner sin
+      const float sq = first ? rnd_bf16(-qp * sn) : rnd_bf16(qp * sn);
+      const float sk = first ? rnd_bf16(-kp * sn) : rnd_bf16(kp * sn);
+      qf[e] = rnd_bf16(rnd_bf16(qo * cs) + sq);
+      kf[e] = rnd_bf16(rnd_bf16(ko * cs) + sk);
+    }
+  }
+  if (wave == 0 && grp == 0) {     // append the new key / value (cache row p)
+    bf16x8 kb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) kb[e] = (bf16)kf[e];
+    const long off = (long)b * a.kv_bs + (long)p * a.kv_ld + (long)h * HD + d0;
+    *reinterpret_cast<bf16x8*>(a.kc + off) = kb;
+    *reinterpret_cast<bf16x8*>(a.vc + off) = vnew;
+  }
+  const bf16* K = a.kc + (long)b * a.kv_bs + (long)h * HD + d0;
+  const bf16* V = a.vc + (long)b * a.kv_bs + (long)h * HD + d0;
+  // Key t belongs to lane group (wave, grp) with t = wave * KPW + grp (mod KPP) in BOTH passes, so a
+  // score is written and read back by the same lanes (LDS as a per-group array, no barrier); four
+  // keys per group are requested before the first is used.
+  constexpr int NB = 4;
+  // ---- pass 1: scores
+  float mx = -INFINITY;
+  for (int t0 = wave * KPW + grp; t0 < T; t0 += KPP * NB) {
+    bf16x8 kv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int t = t0 + j * KPP;
+      if (t < p) kv[j] = *reinterpret_cast<const bf16x8*>(K + (long)t * a.kv_ld);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int t = t0 + j * KPP;
+      float s = 0.f;
+      if (t < p) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += qf[e] * (float)kv[j][e];
+      } else if (t == p) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += qf[e] * kf[e];
+      }
+#pragma unroll
+      for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
+      s *= a.scale;
+      if (t < T) {
+        if (sub == 0) sc[t] = s;
+        mx = fmaxf(mx, s);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) redw[wave] = mx;
+  __syncthreads();
+  mx = redw[0];
+#pragma unroll
+  for (int i = 1; i < NWV; ++i) mx = fmaxf(mx, redw[i]);
+  // ---- pass 2: probabilities, their sum and the weighted values
+  float acc[8], lsum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int t0 = wave * KPW + grp; t0 < T; t0 += KPP * NB) {
+    bf16x8 vv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int t = t0 + j * KPP;
+      if (t < p) vv[j] = *reinterpret_cast<const bf16x8*>(V + (long)t * a.kv_ld);
+      else vv[j] = vnew;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int t = t0 + j * KPP;
+      if (t < T) {
+        const float pr = __expf(sc[t] - mx);
+        lsum += pr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += pr * (float)vv[j][e];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {
+    lsum += __shfl_xor(lsum, o, 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
+  if (grp == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][d0 + e] = acc[e];
+  }
+  if (lane == 0) redw[NWV + wave] = lsum;
+  __syncthreads();
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NWV; ++i) sum += redw[NWV + i];
+  if (tid < HD) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) v += red[i][tid];
+    a.o[(long)b * a.o_bs + (long)h * HD + tid] = (bf16)(v / sum);
+  }
+}
+
+// Greedy token selection and the bookkeeping of a decode step in one launch (HF greedy_search as the
+// reference calls it, modeling.py:959: argmax, pad for finished samples, eos marks a sample
+// finished): one workgroup per sample; the last workgroup to finish advances the step state.
+//   state[0] = position of the token being fed (t_dev of the other decode kernels), state[1] = output
+//   column, state[2] = arrival counter (zero between launches).
+template <typename T>
+__global__ __launch_bounds__(1024) void decode_emit_kernel(const T* logits, long ld, int V, long pad,
+                                                           long eos, int64_t* tok, unsigned char* done,
+                                                           int64_t* out, long out_ld, int32_t* state) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  const int b = blockIdx.x;
+  const T* xr = logits + (long)b * ld;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int c0 = threadIdx.x; c0 < V; c0 += 1024 * 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j * 1024;
+      v[j] = c < V ? (float)xr[c] : -INFINITY;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (v[j] > best) { best = v[j]; idx = c0 + j * 1024; }      // ascending columns: first maximum
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    const int col = state[1];
+    const long nxt = done[b] ? pad : (long)idx;
+    out[(long)b * out_ld + col] = nxt;
+    if (nxt == eos) done[b] = 1;
+    tok[b] = nxt;
+    __threadfence();
+    const int old = __hip_atomic_fetch_add(state + 2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (int)gridDim.x - 1) {          // every sample has read state[1]: advance the step
+      state[0] += 1;
+      state[1] = col + 1;
+      state[2] = 0;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int mk_decode_emit(const void* logits, int64_t ld, int32_t V, int32_t B, int64_t pad,
+                              int64_t eos, int64_t* tok, void* done, int64_t* out, int64_t out_ld,
+                              int32_t* state, int32_t dtype, void* stream) {
+  if (!logits || !tok || !done || !out || !state || V <= 0 || B <= 0 || ld < V) return MK_ERR_BAD_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == MK_BF16)
+    MK_LAUNCH((decode_emit_kernel<bf16>), dim3(B), dim3(1024), 0, st, (const bf16*)logits, (long)ld, V,
+              (long)pad, (long)eos, tok, (unsigned char*)done, out, (long)out_ld, state);
+  else if (dtype == MK_F32)
+    MK_LAUNCH((decode_emit_kernel<float>), dim3(B), dim3(1024), 0, st, (const float*)logits, (long)ld, V,
+              (long)pad, (long)eos, tok, (unsigned char*)done, out, (long)out_ld, state);
+  else return MK_ERR_UNSUPPORTED;
+  return mk_check_launch();
+}
+
+extern "C" int mk_decode_step_attn(const void* q, const void* k_new, const void* v_new, int64_t in_bs,
+                                   const void* cos_t, const void* sin_t, void* k_cache, void* v_cache,
+                                   int64_t kv_ld, int64_t kv_bs, void* o, int64_t o_bs,
+                                   const int32_t* t_dev, int32_t t_max, int32_t B, int32_t H,
+                                   int32_t hd, float scale, int32_t dtype, void* stream) {
+  if (!q || !k_new || !v_new || !cos_t || !sin_t || !k_cache || !v_cache || !o || !t_dev || B <= 0 ||
+      H <= 0 || t_max <= 0)
+    return MK_ERR_BAD_ARG;
+  if (dtype != MK_BF16 || (hd != 16 && hd != 32 && hd != 64 && hd != 128)) return MK_ERR_UNSUPPORTED;
+  if ((long)t_max * 4 > 60 * 1024) return MK_ERR_UNSUPPORTED;     // scores live in LDS
+  const uintptr_t al = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k_new) |
+                       reinterpret_cast<uintptr_t>(v_new) | reinterpret_cast<uintptr_t>(cos_t) |
+                       reinterpret_cast<uintptr_t>(sin_t) | reinterpret_cast<uintptr_t>(k_cache) |
+                       reinterpret_cast<uintptr_t>(v_cache);
+  if ((al & 15) || (in_bs % 8) || (kv_ld % 8) || (kv_bs % 8)) return MK_ERR_UNSUPPORTED;
+  DecodeStepArgs a;
+  a.q = (const bf16*)q; a.kn = (const bf16*)k_new; a.vn = (const bf16*)v_new; a.in_bs = in_bs;
+  a.cos_t = (const bf16*)cos_t; a.sin_t = (const bf16*)sin_t;
+  a.kc = (bf16*)k_cache; a.vc = (bf16*)v_cache; a.kv_ld = kv_ld; a.kv_bs = kv_bs;
+  a.o = (bf16*)o; a.o_bs = o_bs;
+  a.t_dev = t_dev; a.t_max = t_max; a.scale = scale;
+  dim3 grid(H, B), block(512);
+  const size_t lds = (size_t)t_max * 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hd == 128) MK_LAUNCH((decode_step_attn_kernel<128, 8>), grid, block, lds, st, a);
+  else if (hd == 64) MK_LAUNCH((decode_step_attn_kernel<64, 8>), grid, block, lds, st, a);
+  else if (hd == 32) MK_LAUNCH((decode_step_attn_kernel<32, 8>), grid, block, lds, st, a);
+  else MK_LAUNCH((decode_step_attn_kernel<16, 8>), grid, block, lds, st, a);
+  return mk_check_launch();
+}
 
 extern "C" int mk_kv_append(const void* src, void* cache, int32_t cols, int32_t batch, int64_t s_src,
                             int64_t s_cache, int64_t ld_cache, const int32_t* t_dev, int32_t t_max,

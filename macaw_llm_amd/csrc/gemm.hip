@@ -670,42 +670,104 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs g) {
 // and last 6 ... 50 us, so what matters is that EVERY CU pulls from the first microsecond -- and a
 // two-stage register pipeline: the loads of trip i + 1 are in flight under the MFMAs of trip i
 // (U K-blocks of 64 per trip and wave: 2 U weight + 2 U token loads of 16 B per lane).
-template <int NW, int U>
+// PRO: what the token operand is (mk_decode_linear; 0 for mk_gemm):
+//   1  RMSNorm of the A rows, fused: y = w * rnd(x * rstd) with the rounding points of
+//      rmsnorm_fwd_kernel (modeling.py:100-105)
+//   2  SwiGLU of A = [gate | up] ([M, 2K]): x = rnd(rnd(silu(gate)) * up) (swiglu2d_fwd_kernel,
+//      modeling.py:140)
+// With a prologue the workgroup first writes the M prepared token rows to LDS ([M][K + 8] bf16; M x K
+// elements of work per workgroup, from L2) while its first weight fragments are already in flight,
+// and the MFMA token operand is read from there (doing it per fragment in registers repeats the
+// conversion for all 16 token lanes: measured 1.6x SLOWER than the separate kernels).
+template <int NW, int U, int PRO>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char sk_smem[];
   __shared__ float red[NW][4][64];
+  __shared__ float ssq[NW][16];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = l & 15, kq = l >> 4;
   const int n0 = blockIdx.x * 16;
   const bf16* A = reinterpret_cast<const bf16*>(g.A);
   const bf16* B = reinterpret_cast<const bf16*>(g.B);
   const bf16* wp = B + (long)min(n0 + r16, g.N - 1) * g.ldb + 8 * kq;
-  const bf16* xp = A + (long)min(r16, g.M - 1) * g.lda + 8 * kq;
+  const int trow = min(r16, g.M - 1);
+  const bf16* xp = A + (long)trow * g.lda + 8 * kq;
+  const int ldt = g.K + 8;                                  // LDS token row pitch (elements)
+  const bf16* tp = reinterpret_cast<const bf16*>(sk_smem) + trow * ldt + 8 * kq;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int nkb = g.K / 64;
+  constexpr int XN = PRO == 0 ? 2 * U : 1;
   // trip t of wave w covers K blocks w + NW * (t * U + u), u < U (neighbouring waves read
   // neighbouring 128-byte lines of a row)
-  auto load = [&](bf16x8 (&wf)[2 * U], bf16x8 (&xf)[2 * U], int kb) {
+  auto load = [&](bf16x8 (&wf)[2 * U], bf16x8 (&xf)[XN], int kb) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kk = min(kb + u * NW, nkb - 1);       // clamped: the MFMA of a clamped block is skipped
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         wf[2 * u + hh] = *reinterpret_cast<const bf16x8*>(wp + kk * 64 + 32 * hh);
-        xf[2 * u + hh] = *reinterpret_cast<const bf16x8*>(xp + kk * 64 + 32 * hh);
+        if constexpr (PRO == 0) xf[2 * u + hh] = *reinterpret_cast<const bf16x8*>(xp + kk * 64 + 32 * hh);
       }
     }
   };
-  auto mma = [&](const bf16x8 (&wf)[2 * U], const bf16x8 (&xf)[2 * U], int kb) {
+  auto mma = [&](const bf16x8 (&wf)[2 * U], const bf16x8 (&xf)[XN], int kb) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (kb + u * NW < nkb) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * u], xf[2 * u], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * u + 1], xf[2 * u + 1], acc, 0, 0, 0);
+        bf16x8 t0, t1;
+        if constexpr (PRO == 0) {
+          t0 = xf[2 * u]; t1 = xf[2 * u + 1];
+        } else {
+          t0 = *reinterpret_cast<const bf16x8*>(tp + (kb + u * NW) * 64);
+          t1 = *reinterpret_cast<const bf16x8*>(tp + (kb + u * NW) * 64 + 32);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * u], t0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * u + 1], t1, acc, 0, 0, 0);
       }
   };
-  bf16x8 wa[2 * U], xa[2 * U], wb[2 * U], xb[2 * U];
+  bf16x8 wa[2 * U], xa[XN], wb[2 * U], xb[XN];
   constexpr int STEP = NW * U;
   int kb = w;
   if (kb < nkb) load(wa, xa, kb);
+  if constexpr (PRO != 0) {
+    bf16* ts = reinterpret_cast<bf16*>(sk_smem);
+    const int nch = g.K / 8;                                // 16-byte chunks per row
+    for (int m = 0; m < g.M; ++m) {
+      const bf16* xr = A + (long)m * g.lda;
+      float rstd = 1.f;
+      if constexpr (PRO == 1) {
+        float ss = 0.f;
+        for (int c = threadIdx.x; c < nch; c += NW * 64) {
+          const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + c * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss += (float)xv[e] * (float)xv[e];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        __syncthreads();                                    // ssq of the previous row consumed
+        if (l == 0) ssq[w][0] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) tot += ssq[ww][0];   // fixed order: deterministic
+        rstd = rsqrtf(tot / (float)g.K + g.pro_eps);
+      }
+      for (int c = threadIdx.x; c < nch; c += NW * 64) {
+        const bf16x8 av = *reinterpret_cast<const bf16x8*>(xr + c * 8);
+        bf16x8 bv;
+        if constexpr (PRO == 1) bv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(g.pro_w) + c * 8);
+        else bv = *reinterpret_cast<const bf16x8*>(xr + g.K + c * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = (float)av[e], b = (float)bv[e];
+          if constexpr (PRO == 1) o[e] = (bf16)(b * rnd<bf16>(a * rstd));
+          else o[e] = (bf16)(rnd<bf16>(a / (1.f + __expf(-a))) * b);
+        }
+        *reinterpret_cast<bf16x8*>(ts + m * ldt + c * 8) = o;
+      }
+    }
+    __syncthreads();
+  }
   while (kb < nkb) {
     if (kb + STEP < nkb) load(wb, xb, kb + STEP);
     mma(wa, xa, kb);
@@ -949,6 +1011,44 @@ extern "C" int mk_gemm_set_cfg(int cfg) { g_force_cfg = cfg; return MK_OK; }
 namespace mkg {
 int launch_v7(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st);  // gemm_v7.hip
 }
+
+// y[M <= 16, N] = prologue(x) W^T (+ residual): the linear layers of one decode position per sample
+// with the normalisation / activation that precedes them folded into the weight-streaming kernel
+// (one launch instead of two per linear; the hipGraph of a decode step has 5 kernels per layer).
+extern "C" int mk_decode_linear(const void* x, int64_t ldx, const void* W, int64_t ldw, void* y,
+                                int64_t ldy, const void* residual, int64_t ldr, int32_t M, int32_t N,
+                                int32_t K, int32_t prologue, const void* norm_w, float eps,
+                                int32_t dtype, void* stream) {
+  if (!x || !W || !y || M <= 0 || N <= 0 || K <= 0) return MK_ERR_BAD_ARG;
+  if (prologue < 0 || prologue > 2 || (prologue == 1 && !norm_w)) return MK_ERR_BAD_ARG;
+  if (dtype != MK_BF16 || M > 16 || (K % 64) || (ldx % 8) || (ldw % 8) || !aligned16(x) || !aligned16(W) ||
+      (prologue == 1 && !aligned16(norm_w)))
+    return MK_ERR_UNSUPPORTED;
+  GemmArgs g{};
+  g.A = x; g.B = W; g.C = y; g.R = residual;
+  g.M = M; g.N = N; g.K = K;
+  g.lda = ldx; g.ldb = ldw; g.ldc = ldy; g.ldr = ldr;
+  g.alpha = 1.f;
+  g.pro_w = norm_w; g.pro_eps = eps;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int prof = mkp::begin(st, 0, 2.0 * M * N * K, M, N, K, 1, 0, 17 + 10 * prologue);
+  const dim3 g16(mk_cdiv(N, 16));
+  const bool wide = N <= 16 * 256 && K <= 4096;     // as mk_gemm: 16 waves where N / 16 workgroups are few
+  const size_t lds = prologue ? (size_t)M * (K + 8) * 2 : 0;   // prepared token rows
+  if (lds > 40 * 1024) return MK_ERR_UNSUPPORTED;   // (two workgroups per CU must still fit)
+  if (prologue == 0) {
+    if (wide) MK_LAUNCH((gemm_skinny16_kernel<16, 2, 0>), g16, dim3(1024), 0, st, g);
+    else MK_LAUNCH((gemm_skinny16_kernel<8, 2, 0>), g16, dim3(512), 0, st, g);
+  } else if (prologue == 1) {
+    if (wide) MK_LAUNCH((gemm_skinny16_kernel<16, 2, 1>), g16, dim3(1024), lds, st, g);
+    else MK_LAUNCH((gemm_skinny16_kernel<8, 2, 1>), g16, dim3(512), lds, st, g);
+  } else {
+    if (wide) MK_LAUNCH((gemm_skinny16_kernel<16, 2, 2>), g16, dim3(1024), lds, st, g);
+    else MK_LAUNCH((gemm_skinny16_kernel<8, 2, 2>), g16, dim3(512), lds, st, g);
+  }
+  mkp::end(prof, st);
+  return mk_check_launch();
+}
 namespace {
 // Default kernel choice: a small cost model fitted to scripts/gemm_bench.cpp measurements on
 // MI355X (profiles/r02_gemm_shapes.csv; microseconds).  v7: one 256x256 tile per CU and round,
@@ -1037,9 +1137,9 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     if (g_force_cfg >= 12 && g_force_cfg <= 18 && (g_force_cfg == 12 || d->M <= 16)) sk = g_force_cfg;
     mkp::set_cfg(prof, sk);
     const dim3 g16(mk_cdiv(d->N, 16));
-    if (sk == 17) MK_LAUNCH((gemm_skinny16_kernel<8, 2>), g16, dim3(512), 0, st, g);
-    else if (sk == 18) MK_LAUNCH((gemm_skinny16_kernel<16, 2>), g16, dim3(1024), 0, st, g);
-    else if (sk == 13) MK_LAUNCH((gemm_skinny16_kernel<4, 4>), g16, dim3(256), 0, st, g);
+    if (sk == 17) MK_LAUNCH((gemm_skinny16_kernel<8, 2, 0>), g16, dim3(512), 0, st, g);
+    else if (sk == 18) MK_LAUNCH((gemm_skinny16_kernel<16, 2, 0>), g16, dim3(1024), 0, st, g);
+    else if (sk == 13) MK_LAUNCH((gemm_skinny16_kernel<4, 4, 0>), g16, dim3(256), 0, st, g);
     else MK_LAUNCH((gemm_skinny_kernel<8>), dim3(mk_cdiv(d->N, 32)), dim3(512), 0, st, g);
     mkp::end(prof, st);
     return mk_check_launch();

@@ -23,6 +23,7 @@ struct GemmArgs {
   int dp_tiles, split, kt_per_piece;
   int lin_batch;   // 1: batch index is folded into the linear tile index (grid.z == 1)
   int ablate;      // debug only (MK_GEMM_ABLATE): 1 = skip global->LDS, 2 = skip barrier wait
+  const void* pro_w; float pro_eps;   // skinny kernel prologue (mk_decode_linear): RMSNorm weight / eps
   float* ws;       // fp32 slabs [tail tile][piece][64 regs][256 threads]
   int* counters;   // arrival counter per tail tile (zeroed by the launcher)
 };

@@ -292,39 +292,57 @@ def llama_layer_cached(x2, B, Sn, t0, kvc, Tmax, pos, cos, sin, n_heads, eps, wq
     dyn = t_dev is not None
     if dyn and Sn != 1:
         raise ValueError("llama_layer_cached: t_dev is for single-position decode steps")
+    if dyn and wqkv is not None and wgu is not None and ops.decode_linear_ok(x2, wqkv):
+        # five launches: RMSNorm folded into the q|k|v and gate|up weight streams, SwiGLU into down's
+        # (each where the prepared token rows fit the kernel's LDS budget, else the separate kernel)
+        H, hd = n_heads, D // n_heads
+
+        def norm_linear(x, w_ln, W):
+            if ops.decode_linear_ok(x, W, 1):
+                return ops.decode_linear(x, W, 1, w_ln, eps)
+            return ops.linear_fwd(ops.rmsnorm_fwd(x, w_ln, eps)[1], W)
+
+        qkv = norm_linear(x2, ln1, wqkv)
+        att = torch.empty((M, D), dtype=x2.dtype, device=x2.device)
+        ops.decode_step_attn(qkv, qkv, qkv, 3 * D, cos, sin, kvc, t_dev, Tmax, B, H, hd, att,
+                             1.0 / math.sqrt(hd), k_off=D, v_off=2 * D)
+        h1 = ops.linear_fwd(att, wo, residual=x2)
+        gu = norm_linear(h1, ln2, wgu)
+        if ops.decode_linear_ok(gu, wd, 2):
+            return ops.decode_linear(gu, wd, 2, residual=h1)
+        return ops.linear_fwd(ops.swiglu2d_fwd(gu, wg.shape[0]), wd, residual=h1)
     H, hd = n_heads, D // n_heads
     FF = wg.shape[0]
     _, y1, _ = ops.rmsnorm_fwd(x2, ln1, eps)
     ldc = 2 * D
+    att = torch.empty((M, D), dtype=x2.dtype, device=x2.device)
+    scale = 1.0 / math.sqrt(hd)
     if wqkv is not None:
         qkv = ops.linear_fwd(y1, wqkv)
         q = qkv[:, :D]
         ldq = 3 * D
-        ops.rope_(qkv[:, :2 * D], cos, sin, pos, 2 * H, hd)
-        if dyn:
-            ops.kv_append(qkv, kvc, 2 * D, B, ldq, Tmax * ldc, ldc, t_dev, Tmax, src_off=D)
+        if dyn:     # RoPE + cache append + attention of the new position: one launch
+            ops.decode_step_attn(qkv, qkv, qkv, ldq, cos, sin, kvc, t_dev, Tmax, B, H, hd, att, scale,
+                                 k_off=D, v_off=2 * D)
         else:
+            ops.rope_(qkv[:, :2 * D], cos, sin, pos, 2 * H, hd)
             ops.copy2d(qkv, kvc, Sn, 2 * D, ldq, ldc, batch=B, s_src=Sn * ldq, s_dst=Tmax * ldc, src_off=D,
                        dst_off=t0 * ldc)
     else:
         q, k, v = ops.linear_fwd(y1, wq), ops.linear_fwd(y1, wk), ops.linear_fwd(y1, wv)
         ldq = D
-        ops.rope_(q, cos, sin, pos, H, hd)
-        ops.rope_(k, cos, sin, pos, H, hd)
-        # append the new keys / values to the cache rows [t0, t0 + Sn) of every sample
         if dyn:
-            ops.kv_append(k, kvc, D, B, ldq, Tmax * ldc, ldc, t_dev, Tmax)
-            ops.kv_append(v, kvc, D, B, ldq, Tmax * ldc, ldc, t_dev, Tmax, dst_off=D)
+            ops.decode_step_attn(q, k, v, ldq, cos, sin, kvc, t_dev, Tmax, B, H, hd, att, scale)
         else:
+            ops.rope_(q, cos, sin, pos, H, hd)
+            ops.rope_(k, cos, sin, pos, H, hd)
+            # append the new keys / values to the cache rows [t0, t0 + Sn) of every sample
             ops.copy2d(k, kvc, Sn, D, ldq, ldc, batch=B, s_src=Sn * ldq, s_dst=Tmax * ldc, dst_off=t0 * ldc)
             ops.copy2d(v, kvc, Sn, D, ldq, ldc, batch=B, s_src=Sn * ldq, s_dst=Tmax * ldc, dst_off=t0 * ldc + D)
     kc, vc = kvc[:, :, :D], kvc[:, :, D:]
     T = t0 + Sn
-    att = torch.empty((M, D), dtype=x2.dtype, device=x2.device)
-    scale = 1.0 / math.sqrt(hd)
     if dyn:
-        ops.decode_attn(q, kvc, kvc, att, t_dev, 1, Tmax, B, H, hd, ldq, ldc, Tmax * ldc, ldc, Tmax * ldc, D,
-                        scale, v_off=D)
+        pass
     elif flash_ok(x2.dtype, hd):
         ops.flash_attn_fwd(q, kc, vc, att, B, H, Sn, T, hd, ldq, Sn * ldq, ldc, Tmax * ldc, ldc, Tmax * ldc,
                            D, Sn * D, scale, causal=True)

@@ -94,6 +94,10 @@ SIGNATURES = {
     "mk_cross_entropy": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp],
     "mk_cross_entropy_bwd": [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i64, _i32, _vp],
     "mk_argmax_rows": [_vp, _i64, _i32, _i32, _vp, _i32, _vp],
+    "mk_decode_linear": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _f32, _i32, _vp],
+    "mk_decode_emit": [_vp, _i64, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _vp],
+    "mk_decode_step_attn": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i32, _i32,
+                            _i32, _i32, _f32, _i32, _vp],
     "mk_kv_append": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _i32, _vp],
     "mk_decode_attn": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64,
                        _i64, _f32, _i32, _vp],

@@ -413,35 +413,28 @@ class LlamaForCausalLM(LlamaPreTrainedModel):
                                       hidden_states=None, attentions=None)
 
     @torch.no_grad()
-    def _generate_graph(self, run, select, last, emb_w, B, S0, max_new_tokens, eos, pad, dev):
+    def _generate_graph(self, run, logits, last, emb_w, B, S0, max_new_tokens, eos, pad, dev):
         """Decode loop with ONE hipGraph launch per token.  Everything a step needs lives in device
-        memory -- the position (int32 counter read by the RoPE, cache-append and attention kernels),
-        the last token ids, the per-sample finished flags and the output matrix -- so the ~330
-        kernel launches of a step are captured once (after one eager step that also serves as the
-        warm-up) and replayed; the host only looks at the finished flags every few tokens.  Same
-        kernels and arithmetic as the eager loop except the attention kernel (ops.decode_attn)."""
-        t_dev = torch.full((1,), S0, dtype=torch.int32, device=dev)      # position of the token being fed
-        pos = torch.full((B,), S0, dtype=torch.int32, device=dev)
+        memory -- the position (int32 counter read by the fused RoPE + cache append + attention
+        kernel), the last token ids, the per-sample finished flags and the output matrix (all advanced
+        by ops.decode_emit) -- so the launches of a step (5 per layer + 3) are captured once, after
+        one eager step that also serves as the warm-up, and replayed; the host only looks at the
+        finished flags every few tokens."""
+        state = torch.tensor([S0, 0, 0, 0], dtype=torch.int32, device=dev)   # position fed, output column, 0
+        t_dev = state[:1]
         tok = torch.zeros(B, dtype=torch.long, device=dev)
         done = torch.zeros(B, dtype=torch.bool, device=dev)
-        col = torch.zeros((B, 1), dtype=torch.long, device=dev)
         out_buf = torch.full((B, max_new_tokens), pad, dtype=torch.long, device=dev)
-        padv = torch.full((B,), pad, dtype=torch.long, device=dev)
+        V = self.lm_head.weight.shape[0]
 
-        def emit(h_last):
-            nxt = torch.where(done, padv, select(h_last))
-            out_buf.scatter_(1, col, nxt.view(B, 1))
-            done.logical_or_(nxt == eos)
-            col.add_(1)
-            tok.copy_(nxt)
+        def emit(h_last):                # argmax, pad / eos handling, output column, position += 1
+            ops.decode_emit(logits(h_last), V, pad, eos, tok, done, out_buf, state)
 
         def step():
-            h = run(ops.embedding_fwd(emb_w, tok), 1, 0, pos=pos, t_dev=t_dev)
-            emit(h)
-            t_dev.add_(1)
-            pos.add_(1)
+            emit(run(ops.embedding_fwd(emb_w, tok), 1, 0, pos=t_dev, t_dev=t_dev))
 
-        emit(last)                       # token 0 (from the prefill)
+        emit(last)                       # token 0 (from the prefill) ...
+        state[0] = S0                    # ... is the one fed at position S0
         emitted = 1
         if not bool(done.all()):
             step()                       # token 1: eager (kernel attributes, allocator pools, workspace)
@@ -487,9 +480,14 @@ class LlamaForCausalLM(LlamaPreTrainedModel):
         V = self.lm_head.weight.shape[0]
         out = []
 
-        def select(h_last):       # h_last [B, D] -> next token ids [B]
+        def logits(h_last):       # h_last [B, D] -> [B, V] (final norm folded into the lm_head stream)
+            if h_last.is_contiguous() and ops.decode_linear_ok(h_last, self.lm_head.weight, 1):
+                return ops.decode_linear(h_last, self.lm_head.weight, 1, self.model.norm.weight, eps)
             _, y, _ = ops.rmsnorm_fwd(h_last, self.model.norm.weight, eps)
-            return ops.argmax_rows(ops.linear_fwd(y, self.lm_head.weight), V)
+            return ops.linear_fwd(y, self.lm_head.weight)
+
+        def select(h_last):       # h_last [B, D] -> next token ids [B]
+            return ops.argmax_rows(logits(h_last), V)
 
         if not use_cache:
             emb = inputs_embeds.contiguous()
@@ -540,7 +538,7 @@ class LlamaForCausalLM(LlamaPreTrainedModel):
         hd = D // layers[0].self_attn.num_heads
         if (decode_graph and max_new_tokens > 2 and ops.decode_attn_ok(dtype, hd, Tmax)
                 and not os.environ.get("MACAW_NO_DECODE_GRAPH")):
-            return self._generate_graph(run, select, last, emb_w, B, S0, max_new_tokens, eos_token_id, pad, dev)
+            return self._generate_graph(run, logits, last, emb_w, B, S0, max_new_tokens, eos_token_id, pad, dev)
         for t in range(max_new_tokens):
             nxt = torch.where(done, torch.full((B,), pad, dtype=torch.long, device=dev), select(last))
             out.append(nxt)

@@ -423,6 +423,52 @@ def decode_attn(q, k, v, out, t_dev, t_add, t_max, B, H, hd, q_bs, k_ld, k_bs, v
     return out
 
 
+def decode_linear(x, W, prologue=0, norm_w=None, eps=0.0, residual=None, out=None):
+    """y[M <= 16, N] = prologue(x) W^T (+ residual) in one launch: prologue 1 = RMSNorm(x; norm_w, eps),
+    2 = SwiGLU of x = [gate | up] ([M, 2K]); W [N, K] row-major"""
+    lib = _L.load()
+    M = x.shape[0]
+    N, K = W.shape
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _L.check(lib.mk_decode_linear(_p(x), _rowmajor(x), _p(W), _rowmajor(W), _p(out), _rowmajor(out),
+                                  _p(residual), _rowmajor(residual) if residual is not None else 0, M, N, K,
+                                  prologue, _p(norm_w), eps, dt(x), _st()), "mk_decode_linear")
+    return out
+
+
+def decode_linear_ok(x, W, prologue=0):
+    """mk_decode_linear's domain; with a prologue the prepared token rows must fit 40 KiB of LDS"""
+    M, K = x.shape[0], W.shape[1]
+    return (x.dtype == torch.bfloat16 and M <= 16 and K % 64 == 0 and W.is_contiguous()
+            and (prologue == 0 or M * (K + 8) * 2 <= 40 * 1024))
+
+
+def decode_emit(logits, V, pad, eos, tok, done, out, state):
+    """greedy selection + step bookkeeping in one launch (see mk_decode_emit): logits [B, >= V]
+    row-major, tok int64 [B], done bool [B], out int64 [B, n], state int32 [>= 3] = (position, output
+    column, 0)"""
+    lib = _L.load()
+    B = logits.shape[0]
+    _L.check(lib.mk_decode_emit(_p(logits), _rowmajor(logits), V, B, pad, eos, _p(tok), _p(done), _p(out),
+                                out.stride(0), _p(state), dt(logits), _st()), "mk_decode_emit")
+
+
+def decode_step_attn(q, k_new, v_new, in_bs, cos_t, sin_t, cache, t_dev, t_max, B, H, hd, out, scale,
+                     q_off=0, k_off=0, v_off=0):
+    """RoPE(q, k_new) at position *t_dev + append [k_new | v_new] to cache [B, t_max, 2 * H * hd] row
+    *t_dev + attention of q over keys 0 ... *t_dev, one launch (q / k_new / v_new may be slices of one
+    fused [B, 3D] buffer: element offsets q_off / k_off / v_off)"""
+    lib = _L.load()
+    es = q.element_size()
+    D = H * hd
+    _L.check(lib.mk_decode_step_attn(_p(q) + q_off * es, _p(k_new) + k_off * es, _p(v_new) + v_off * es,
+                                     in_bs, _p(cos_t), _p(sin_t), _p(cache), _p(cache) + D * es, 2 * D,
+                                     t_max * 2 * D, _p(out), D, _p(t_dev), t_max, B, H, hd, scale, dt(q),
+                                     _st()), "mk_decode_step_attn")
+    return out
+
+
 def decode_attn_ok(dtype, hd, t_max):
     return dtype == torch.bfloat16 and hd in (16, 32, 64, 128) and t_max * 4 <= 60 * 1024
 

@@ -672,3 +672,100 @@ def test_decode_attn_and_kv_append_with_device_position(hd, H, B, T):
     ops.decode_attn(qkv, cache, cache, out, t_dev, 1, Tmax, B, H, hd, 3 * D, 2 * D, Tmax * 2 * D, 2 * D,
                     Tmax * 2 * D, D, scale, v_off=D)
     assert torch.allclose(out.float(), cache[:, 0, D:].float(), atol=1e-6)   # one key: output = its value
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hd,H,B,T", [(128, 32, 1, 173), (128, 4, 2, 1), (64, 8, 2, 65), (32, 4, 2, 300), (16, 4, 3, 40)])
+def test_decode_step_attn_equals_rope_append_attention(hd, H, B, T):
+    """mk_decode_step_attn = mk_rope (q and k heads) + cache append + attention over keys 0 ... p with
+    p read from device memory: rotated key / value rows bit-identical to the separate kernels, output
+    against an fp32 reference"""
+    from macaw_llm_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3 * hd + T)
+    D, Tmax, p = H * hd, T + 5, T - 1
+    cache = torch.zeros((B, Tmax, 2 * D), dtype=torch.bfloat16, device=dev)
+    cache[:, :p] = torch.randn((B, p, 2 * D), device=dev).to(torch.bfloat16)
+    qkv = torch.randn((B, 3 * D), device=dev).to(torch.bfloat16)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    ang = torch.cat((torch.outer(torch.arange(Tmax).float(), inv),) * 2, dim=-1)
+    cos, sin = ang.cos().to(dev).to(torch.bfloat16), ang.sin().to(dev).to(torch.bfloat16)
+    t_dev = torch.tensor([p], dtype=torch.int32, device=dev)
+    # separate kernels
+    ref_qkv = qkv.clone()
+    pos = torch.full((B,), p, dtype=torch.int32, device=dev)
+    ops.rope_(ref_qkv[:, :2 * D], cos, sin, pos, 2 * H, hd)
+    want_cache = cache.clone()
+    want_cache[:, p] = ref_qkv[:, D:]
+    out = torch.empty((B, D), dtype=torch.bfloat16, device=dev)
+    scale = 1.0 / hd ** 0.5
+    ops.decode_step_attn(qkv, qkv, qkv, 3 * D, cos, sin, cache, t_dev, Tmax, B, H, hd, out, scale,
+                         k_off=D, v_off=2 * D)
+    assert torch.equal(cache, want_cache)
+    q = ref_qkv[:, :D].float().view(B, H, 1, hd)
+    k = want_cache[:, :T, :D].float().view(B, T, H, hd).permute(0, 2, 1, 3)
+    v = want_cache[:, :T, D:].float().view(B, T, H, hd).permute(0, 2, 1, 3)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).reshape(B, D)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(1, 12288, 4096), (3, 4096, 4096), (16, 520, 704), (4, 32007, 4096), (1, 4096, 11008)])
+def test_decode_linear_prologues_match_the_separate_kernels(M, N, K):
+    """mk_decode_linear with the RMSNorm / SwiGLU prologue against rmsnorm_fwd / swiglu2d_fwd followed
+    by the plain linear (same rounding points: the results may differ only through the order of the
+    fp32 sum of squares), and against fp32 math"""
+    from macaw_llm_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + N + K)
+    x = _rand((M, K), torch.bfloat16, g).to(dev)
+    W = (_rand((N, K), torch.bfloat16, g).float() * 0.05).to(torch.bfloat16).to(dev)
+    res = _rand((M, N), torch.bfloat16, g).to(dev)
+    nw = (1.0 + 0.1 * _rand((K,), torch.float32, g)).to(torch.bfloat16).to(dev)
+    # plain
+    y0 = ops.decode_linear(x, W, residual=res)
+    _close(y0, x.float().cpu() @ W.float().cpu().t() + res.float().cpu(), torch.bfloat16, scale=math.sqrt(K) * 0.05 + 1.0,
+           what="decode_linear plain")
+    # RMSNorm prologue
+    _, yn, _ = ops.rmsnorm_fwd(x, nw, 1e-6)
+    want = ops.linear_fwd(yn, W)
+    got = ops.decode_linear(x, W, 1, nw, 1e-6)
+    d = (got.float() - want.float()).abs().max().item()
+    assert d <= 0.02 * want.float().abs().max().item() + 1e-3, d
+    assert (got == want).float().mean().item() > 0.98           # a differing rstd ulp flips few roundings
+    # SwiGLU prologue: x2 = [gate | up]
+    gu = _rand((M, 2 * K), torch.bfloat16, g).to(dev)
+    a = ops.swiglu2d_fwd(gu, K)
+    want = ops.linear_fwd(a, W, residual=res)
+    got = ops.decode_linear(gu, W, 2, residual=res)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+def test_decode_emit_argmax_pad_eos_and_step_state():
+    """mk_decode_emit: first argmax per row, pad for finished samples, eos marks a sample finished,
+    output column and position advance exactly once per launch"""
+    from macaw_llm_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    B, V, ld = 5, 32007, 32064
+    logits = torch.randn((B, ld), device=dev).to(torch.bfloat16)
+    logits[:, V:] = 100.0                                   # pad columns must be ignored
+    logits[1, 777] = logits[1, 20001] = 50.0                # tie: lowest index
+    logits[2, 9] = 60.0                                     # will be eos
+    tok = torch.zeros(B, dtype=torch.long, device=dev)
+    done = torch.zeros(B, dtype=torch.bool, device=dev)
+    done[3] = True
+    out = torch.full((B, 4), -1, dtype=torch.long, device=dev)
+    state = torch.tensor([144, 1, 0, 0], dtype=torch.int32, device=dev)
+    ops.decode_emit(logits, V, 106, 9, tok, done, out, state)
+    want = logits[:, :V].float().argmax(1)
+    want[1] = 777
+    want[3] = 106
+    assert torch.equal(out[:, 1], want) and torch.equal(tok, want)
+    assert torch.equal(out[:, 0], torch.full((B,), -1, device=dev)) and torch.equal(out[:, 2:], torch.full((B, 2), -1, device=dev))
+    assert done.tolist() == [False, False, True, True, False]
+    assert state.tolist() == [145, 2, 0, 0]
+    ops.decode_emit(logits, V, 106, 9, tok, done, out, state)
+    assert out[2, 2].item() == 106 and state.tolist() == [146, 3, 0, 0]
