@@ -679,7 +679,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs g) {
 // elements of work per workgroup, from L2) while its first weight fragments are already in flight,
 // and the MFMA token operand is read from there (doing it per fragment in registers repeats the
 // conversion for all 16 token lanes: measured 1.6x SLOWER than the separate kernels).
-template <int NW, int U, int PRO>
+template <int NW, int U, int PRO, int NBUF = 2>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char sk_smem[];
   __shared__ float red[NW][4][64];
@@ -724,10 +724,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs g) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * u + 1], t1, acc, 0, 0, 0);
       }
   };
-  bf16x8 wa[2 * U], xa[XN], wb[2 * U], xb[XN];
+  // ring of NBUF register buffers: NBUF - 1 trips of this wave are in flight under the MFMAs of one
+  bf16x8 wbuf[NBUF][2 * U], xbuf[NBUF][XN];
   constexpr int STEP = NW * U;
   int kb = w;
-  if (kb < nkb) load(wa, xa, kb);
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i)
+    if (kb + i * STEP < nkb) load(wbuf[i], xbuf[i], kb + i * STEP);
   if constexpr (PRO != 0) {
     bf16* ts = reinterpret_cast<bf16*>(sk_smem);
     const int nch = g.K / 8;                                // 16-byte chunks per row
@@ -769,13 +772,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs g) {
     __syncthreads();
   }
   while (kb < nkb) {
-    if (kb + STEP < nkb) load(wb, xb, kb + STEP);
-    mma(wa, xa, kb);
-    kb += STEP;
-    if (kb >= nkb) break;
-    if (kb + STEP < nkb) load(wa, xa, kb + STEP);
-    mma(wb, xb, kb);
-    kb += STEP;
+#pragma unroll
+    for (int i = 0; i < NBUF; ++i) {
+      if (kb + (NBUF - 1) * STEP < nkb) load(wbuf[(i + NBUF - 1) % NBUF], xbuf[(i + NBUF - 1) % NBUF], kb + (NBUF - 1) * STEP);
+      mma(wbuf[i], xbuf[i], kb);
+      kb += STEP;
+      if (kb >= nkb) break;
+    }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[w][e][l] = acc[e];
@@ -1038,13 +1041,13 @@ extern "C" int mk_decode_linear(const void* x, int64_t ldx, const void* W, int64
   if (lds > 40 * 1024) return MK_ERR_UNSUPPORTED;   // (two workgroups per CU must still fit)
   if (prologue == 0) {
     if (wide) MK_LAUNCH((gemm_skinny16_kernel<16, 2, 0>), g16, dim3(1024), 0, st, g);
-    else MK_LAUNCH((gemm_skinny16_kernel<8, 2, 0>), g16, dim3(512), 0, st, g);
+    else MK_LAUNCH((gemm_skinny16_kernel<8, 2, 0, 3>), g16, dim3(512), 0, st, g);
   } else if (prologue == 1) {
     if (wide) MK_LAUNCH((gemm_skinny16_kernel<16, 2, 1>), g16, dim3(1024), lds, st, g);
-    else MK_LAUNCH((gemm_skinny16_kernel<8, 2, 1>), g16, dim3(512), lds, st, g);
+    else MK_LAUNCH((gemm_skinny16_kernel<8, 2, 1, 3>), g16, dim3(512), lds, st, g);
   } else {
     if (wide) MK_LAUNCH((gemm_skinny16_kernel<16, 2, 2>), g16, dim3(1024), lds, st, g);
-    else MK_LAUNCH((gemm_skinny16_kernel<8, 2, 2>), g16, dim3(512), lds, st, g);
+    else MK_LAUNCH((gemm_skinny16_kernel<8, 2, 2, 3>), g16, dim3(512), lds, st, g);
   }
   mkp::end(prof, st);
   return mk_check_launch();
@@ -1137,9 +1140,9 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     if (g_force_cfg >= 12 && g_force_cfg <= 18 && (g_force_cfg == 12 || d->M <= 16)) sk = g_force_cfg;
     mkp::set_cfg(prof, sk);
     const dim3 g16(mk_cdiv(d->N, 16));
-    if (sk == 17) MK_LAUNCH((gemm_skinny16_kernel<8, 2, 0>), g16, dim3(512), 0, st, g);
+    if (sk == 17) MK_LAUNCH((gemm_skinny16_kernel<8, 2, 0, 3>), g16, dim3(512), 0, st, g);
     else if (sk == 18) MK_LAUNCH((gemm_skinny16_kernel<16, 2, 0>), g16, dim3(1024), 0, st, g);
-    else if (sk == 13) MK_LAUNCH((gemm_skinny16_kernel<4, 4, 0>), g16, dim3(256), 0, st, g);
+    else if (sk == 13) MK_LAUNCH((gemm_skinny16_kernel<8, 2, 0, 2>), g16, dim3(512), 0, st, g);
     else MK_LAUNCH((gemm_skinny_kernel<8>), dim3(mk_cdiv(d->N, 32)), dim3(512), 0, st, g);
     mkp::end(prof, st);
     return mk_check_launch();

@@ -306,7 +306,7 @@ def llama_layer_cached(x2, B, Sn, t0, kvc, Tmax, pos, cos, sin, n_heads, eps, wq
         att = torch.empty((M, D), dtype=x2.dtype, device=x2.device)
         ops.decode_step_attn(qkv, qkv, qkv, 3 * D, cos, sin, kvc, t_dev, Tmax, B, H, hd, att,
                              1.0 / math.sqrt(hd), k_off=D, v_off=2 * D)
-        h1 = ops.linear_fwd(att, wo, residual=x2)
+        h1 = ops.decode_linear(att, wo, residual=x2)
         gu = norm_linear(h1, ln2, wgu)
         if ops.decode_linear_ok(gu, wd, 2):
             return ops.decode_linear(gu, wd, 2, residual=h1)

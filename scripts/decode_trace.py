@@ -1,5 +1,5 @@
 """Reads a rocprofv3 kernel-trace CSV of scripts/bench_generate.py-style decoding and reports ONE
-decode step (between two consecutive argmax kernels near the end): kernels, wall, busy, gaps."""
+decode step (between two consecutive token-selection kernels near the end): kernels, wall, busy, gaps."""
 import csv
 import sys
 
@@ -8,7 +8,7 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-am = [i for i, r in enumerate(rows) if "argmax" in r[2]]
+am = [i for i, r in enumerate(rows) if "argmax" in r[2] or "decode_emit" in r[2]]
 a, b = am[-3], am[-2]
 step = rows[a + 1:b + 1]
 t0, t1 = rows[a][1], step[-1][1]

@@ -711,7 +711,8 @@ def test_decode_step_attn_equals_rope_append_attention(hd, H, B, T):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(1, 12288, 4096), (3, 4096, 4096), (16, 520, 704), (4, 32007, 4096), (1, 4096, 11008)])
+@pytest.mark.parametrize("M,N,K", [(1, 12288, 4096), (3, 4096, 4096), (16, 520, 704), (4, 32007, 4096), (1, 4096, 11008),
+                                   (1, 1001, 704), (1, 32007, 5120), (1, 5120, 13824)])
 def test_decode_linear_prologues_match_the_separate_kernels(M, N, K):
     """mk_decode_linear with the RMSNorm / SwiGLU prologue against rmsnorm_fwd / swiglu2d_fwd followed
     by the plain linear (same rounding points: the results may differ only through the order of the
