@@ -141,8 +141,6 @@ MK_DEV float rnd_bf16(float x) { return rnd<bf16>(x); }
 template <int HD, int NWV>
 __global__ __launch_bounds__(NWV * 64) void decode_step_attn_kernel(DecodeStepArgs a) {
   constexpr int LPK = HD / 8, KPW = 64 / LPK, KPP = NWV * KPW;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* sc = reinterpret_cast<float*>(smem_raw);
   __shared__ float red[NWV][HD];
   __shared__ float redw[2 * NWV];
   const int h = blockIdx.x, b = blockIdx.y;
@@ -182,19 +180,26 @@ __global__ __launch_bounds__(NWV * 64) void decode_step_attn_kernel(DecodeStepAr
   }
   const bf16* K = a.kc + (long)b * a.kv_bs + (long)h * HD + d0;
   const bf16* V = a.vc + (long)b * a.kv_bs + (long)h * HD + d0;
-  // Key t belongs to lane group (wave, grp) with t = wave * KPW + grp (mod KPP) in BOTH passes, so a
-  // score is written and read back by the same lanes (LDS as a per-group array, no barrier); four
-  // keys per group are requested before the first is used.
-  constexpr int NB = 4;
-  // ---- pass 1: scores
-  float mx = -INFINITY;
+  // Key t belongs to lane group (wave, grp), t = wave * KPW + grp (mod KPP); NB keys per group and
+  // trip, their K AND V rows requested together (one memory round trip per KPP * NB keys: a 7B decode
+  // step at a few hundred tokens is latency, not bandwidth), online softmax across trips.
+  constexpr int NB = 8;
+  float m_run = -INFINITY, lsum = 0.f, acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
   for (int t0 = wave * KPW + grp; t0 < T; t0 += KPP * NB) {
-    bf16x8 kv[NB];
+    bf16x8 kv[NB], vv[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int t = t0 + j * KPP;
-      if (t < p) kv[j] = *reinterpret_cast<const bf16x8*>(K + (long)t * a.kv_ld);
+      if (t < p) {
+        kv[j] = *reinterpret_cast<const bf16x8*>(K + (long)t * a.kv_ld);
+        vv[j] = *reinterpret_cast<const bf16x8*>(V + (long)t * a.kv_ld);
+      } else {
+        vv[j] = vnew;
+      }
     }
+    float sj[NB], mt = m_run;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int t = t0 + j * KPP;
@@ -208,13 +213,24 @@ __global__ __launch_bounds__(NWV * 64) void decode_step_attn_kernel(DecodeStepAr
       }
 #pragma unroll
       for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
-      s *= a.scale;
-      if (t < T) {
-        if (sub == 0) sc[t] = s;
-        mx = fmaxf(mx, s);
-      }
+      sj[j] = t < T ? s * a.scale : -INFINITY;
+      mt = fmaxf(mt, sj[j]);
     }
+    const float corr = __expf(m_run - mt);       // (0 on the first trip: m_run = -inf, mt finite)
+    lsum *= corr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= corr;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float pr = __expf(sj[j] - mt);       // exp(-inf) = 0 for keys past the end
+      lsum += pr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += pr * (float)vv[j][e];
+    }
+    m_run = mt;
   }
+  // merge the lane groups: common maximum, then rescaled sums
+  float mx = m_run;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   if (lane == 0) redw[wave] = mx;
@@ -222,28 +238,11 @@ __global__ __launch_bounds__(NWV * 64) void decode_step_attn_kernel(DecodeStepAr
   mx = redw[0];
 #pragma unroll
   for (int i = 1; i < NWV; ++i) mx = fmaxf(mx, redw[i]);
-  // ---- pass 2: probabilities, their sum and the weighted values
-  float acc[8], lsum = 0.f;
+  {
+    const float corr = __expf(m_run - mx);       // groups without a key: m_run = -inf -> 0
+    lsum *= corr;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  for (int t0 = wave * KPW + grp; t0 < T; t0 += KPP * NB) {
-    bf16x8 vv[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int t = t0 + j * KPP;
-      if (t < p) vv[j] = *reinterpret_cast<const bf16x8*>(V + (long)t * a.kv_ld);
-      else vv[j] = vnew;
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int t = t0 + j * KPP;
-      if (t < T) {
-        const float pr = __expf(sc[t] - mx);
-        lsum += pr;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += pr * (float)vv[j][e];
-      }
-    }
+    for (int e = 0; e < 8; ++e) acc[e] *= corr;
   }
 #pragma unroll
   for (int o = LPK; o < 64; o <<= 1) {
@@ -346,7 +345,6 @@ extern "C" int mk_decode_step_attn(const void* q, const void* k_new, const void*
       H <= 0 || t_max <= 0)
     return MK_ERR_BAD_ARG;
   if (dtype != MK_BF16 || (hd != 16 && hd != 32 && hd != 64 && hd != 128)) return MK_ERR_UNSUPPORTED;
-  if ((long)t_max * 4 > 60 * 1024) return MK_ERR_UNSUPPORTED;     // scores live in LDS
   const uintptr_t al = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k_new) |
                        reinterpret_cast<uintptr_t>(v_new) | reinterpret_cast<uintptr_t>(cos_t) |
                        reinterpret_cast<uintptr_t>(sin_t) | reinterpret_cast<uintptr_t>(k_cache) |
@@ -359,7 +357,7 @@ extern "C" int mk_decode_step_attn(const void* q, const void* k_new, const void*
   a.o = (bf16*)o; a.o_bs = o_bs;
   a.t_dev = t_dev; a.t_max = t_max; a.scale = scale;
   dim3 grid(H, B), block(512);
-  const size_t lds = (size_t)t_max * 4;
+  const size_t lds = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (hd == 128) MK_LAUNCH((decode_step_attn_kernel<128, 8>), grid, block, lds, st, a);
   else if (hd == 64) MK_LAUNCH((decode_step_attn_kernel<64, 8>), grid, block, lds, st, a);

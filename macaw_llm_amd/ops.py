@@ -54,6 +54,12 @@ def _workspace(device):
     """per-(device, stream) scratch for the GEMM stream-K tail (partials + counters)"""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
+    if ws is None and torch.cuda.is_current_stream_capturing():
+        # a graph capture runs on its own stream: use the device's existing scratch (the captured
+        # kernels are serialised) instead of allocating + zero-filling one inside the graph
+        for (dev_i, _), w in _WS.items():
+            if dev_i == device.index:
+                return w
     if ws is None:
         ws = _WS[key] = torch.empty(WS_BYTES, dtype=torch.uint8, device=device)
         # the first 4 KiB are the stream-K arrival counters: zero once, the kernels leave them zero
