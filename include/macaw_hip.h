@@ -274,7 +274,8 @@ int mk_argmax_rows(const void* x, int64_t ld, int32_t rows, int32_t cols, int64_
  *   T = clamp(*t_dev + t_add, 1, t_max); one query row per (sample, head); q / o rows are
  *   [H * hd] at batch strides q_bs / o_bs, keys and values [t_max][H * hd] at pitches k_ld / v_ld and
  *   batch strides k_bs / v_bs.  bf16, hd in {16, 32, 64, 128}, t_max <= 15360 (scores in LDS). */
-/* mk_decode_linear: y[M][N] = prologue(x) W^T (+ residual) for M <= 16 token rows (bf16, K % 64 == 0,
+/* mk_decode_linear: y[M][N] = prologue(x) W^T (+ residual) for M <= 16 token rows (M <= 32 without a
+ *   prologue; bf16, K % 64 == 0,
  *   16-byte aligned rows), the weight-streaming kernel of mk_gemm's M <= 16 path with the operation
  *   that precedes the linear folded in: prologue 0 = none (x [M][K]); 1 = RMSNorm (x [M][K], norm_w
  *   [K], eps: y = (norm_w * rnd(x * rstd)) W^T, modeling.py:100-105); 2 = SwiGLU (x [M][2K] =

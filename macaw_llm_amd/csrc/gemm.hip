@@ -679,10 +679,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs g) {
 // elements of work per workgroup, from L2) while its first weight fragments are already in flight,
 // and the MFMA token operand is read from there (doing it per fragment in registers repeats the
 // conversion for all 16 token lanes: measured 1.6x SLOWER than the separate kernels).
-template <int NW, int U, int PRO, int NBUF = 2>
+// MT = 2: two tiles of 16 token rows (M <= 32) share every weight fragment (PRO = 0 only).
+template <int NW, int U, int PRO, int NBUF = 2, int MT = 1>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs g) {
+  static_assert(MT == 1 || PRO == 0, "two token tiles: plain token operand only");
   extern __shared__ __attribute__((aligned(16))) char sk_smem[];
-  __shared__ float red[NW][4][64];
+  __shared__ float red[NW][4 * MT][64];
   __shared__ float ssq[NW][16];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = l & 15, kq = l >> 4;
   const int n0 = blockIdx.x * 16;
@@ -691,11 +693,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs g) {
   const bf16* wp = B + (long)min(n0 + r16, g.N - 1) * g.ldb + 8 * kq;
   const int trow = min(r16, g.M - 1);
   const bf16* xp = A + (long)trow * g.lda + 8 * kq;
+  const bf16* xp2 = A + (long)min(16 + r16, g.M - 1) * g.lda + 8 * kq;   // MT == 2: token rows 16 ... 31
   const int ldt = g.K + 8;                                  // LDS token row pitch (elements)
   const bf16* tp = reinterpret_cast<const bf16*>(sk_smem) + trow * ldt + 8 * kq;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
   const int nkb = g.K / 64;
-  constexpr int XN = PRO == 0 ? 2 * U : 1;
+  constexpr int XN = PRO == 0 ? 2 * U * MT : 1;
   // trip t of wave w covers K blocks w + NW * (t * U + u), u < U (neighbouring waves read
   // neighbouring 128-byte lines of a row)
   auto load = [&](bf16x8 (&wf)[2 * U], bf16x8 (&xf)[XN], int kb) {
@@ -706,6 +709,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs g) {
       for (int hh = 0; hh < 2; ++hh) {
         wf[2 * u + hh] = *reinterpret_cast<const bf16x8*>(wp + kk * 64 + 32 * hh);
         if constexpr (PRO == 0) xf[2 * u + hh] = *reinterpret_cast<const bf16x8*>(xp + kk * 64 + 32 * hh);
+        if constexpr (MT == 2) xf[2 * U + 2 * u + hh] = *reinterpret_cast<const bf16x8*>(xp2 + kk * 64 + 32 * hh);
       }
     }
   };
@@ -722,6 +726,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs g) {
         }
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * u], t0, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * u + 1], t1, acc, 0, 0, 0);
+        if constexpr (MT == 2) {
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * u], xf[2 * U + 2 * u], acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * u + 1], xf[2 * U + 2 * u + 1], acc2, 0, 0, 0);
+        }
       }
   };
   // ring of NBUF register buffers: NBUF - 1 trips of this wave are in flight under the MFMAs of one
@@ -781,18 +789,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs g) {
     }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) red[w][e][l] = acc[e];
+  for (int e = 0; e < 4; ++e) {
+    red[w][e][l] = acc[e];
+    if constexpr (MT == 2) red[w][4 + e][l] = acc2[e];
+  }
   __syncthreads();
   // D[i = weight row][j = token]: lane holds j = l & 15, i = 4 * (l >> 4) + e
   float alpha = g.alpha;
   bf16* C = reinterpret_cast<bf16*>(g.C);
   const bf16* Rp = reinterpret_cast<const bf16*>(g.R);
-  for (int t = threadIdx.x; t < 256; t += NW * 64) {
-    const int e = t >> 6, ll = t & 63;
+  for (int t = threadIdx.x; t < 256 * MT; t += NW * 64) {
+    const int e = (t >> 6) & 3, ll = t & 63, mt = t >> 8;
     float v = 0.f;
 #pragma unroll
-    for (int ww = 0; ww < NW; ++ww) v += red[ww][e][ll];   // fixed order: deterministic
-    const int m = ll & 15, n = n0 + 4 * (ll >> 4) + e;
+    for (int ww = 0; ww < NW; ++ww) v += red[ww][4 * mt + e][ll];   // fixed order: deterministic
+    const int m = 16 * mt + (ll & 15), n = n0 + 4 * (ll >> 4) + e;
     if (m >= g.M || n >= g.N) continue;
     v *= alpha;
     if (g.bias_mode == 1) v += (float)reinterpret_cast<const bf16*>(g.bias)[n];
@@ -1024,7 +1035,7 @@ extern "C" int mk_decode_linear(const void* x, int64_t ldx, const void* W, int64
                                 int32_t dtype, void* stream) {
   if (!x || !W || !y || M <= 0 || N <= 0 || K <= 0) return MK_ERR_BAD_ARG;
   if (prologue < 0 || prologue > 2 || (prologue == 1 && !norm_w)) return MK_ERR_BAD_ARG;
-  if (dtype != MK_BF16 || M > 16 || (K % 64) || (ldx % 8) || (ldw % 8) || !aligned16(x) || !aligned16(W) ||
+  if (dtype != MK_BF16 || M > (prologue ? 16 : 32) || (K % 64) || (ldx % 8) || (ldw % 8) || !aligned16(x) || !aligned16(W) ||
       (prologue == 1 && !aligned16(norm_w)))
     return MK_ERR_UNSUPPORTED;
   GemmArgs g{};
@@ -1039,7 +1050,9 @@ extern "C" int mk_decode_linear(const void* x, int64_t ldx, const void* W, int64
   const bool wide = N <= 16 * 256 && K <= 4096;     // as mk_gemm: 16 waves where N / 16 workgroups are few
   const size_t lds = prologue ? (size_t)M * (K + 8) * 2 : 0;   // prepared token rows
   if (lds > 40 * 1024) return MK_ERR_UNSUPPORTED;   // (two workgroups per CU must still fit)
-  if (prologue == 0) {
+  if (M > 16) {
+    MK_LAUNCH((gemm_skinny16_kernel<8, 2, 0, 2, 2>), g16, dim3(512), 0, st, g);
+  } else if (prologue == 0) {
     if (wide) MK_LAUNCH((gemm_skinny16_kernel<16, 2, 0>), g16, dim3(1024), 0, st, g);
     else MK_LAUNCH((gemm_skinny16_kernel<8, 2, 0, 3>), g16, dim3(512), 0, st, g);
   } else if (prologue == 1) {
@@ -1129,18 +1142,19 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
                               d->K * (fp8 ? 2 : 1), nbatch, d->a_red_major * 2 + d->b_red_major, -1);
   // (measured on generate(): B = 1: 7.5 -> 6.1 ms/token, B = 8: 7.2 -> 6.5; at B = 32 the 32 distinct
   // token rows re-read per workgroup cost more than the tile kernel's wasted rows: 8.6 vs 8.0)
-  static const int skinny_max = [] { const char* e = getenv("MK_GEMM_SKINNY_MAX_M"); return e ? atoi(e) : 16; }();
+  static const int skinny_max = [] { const char* e = getenv("MK_GEMM_SKINNY_MAX_M"); return e ? atoi(e) : 32; }();
   if (d->dtype == MK_BF16 && !fp8 && d->M <= 32 && d->M <= skinny_max && !d->a_red_major && !d->b_red_major && nbatch == 1 &&
       (d->K % 64) == 0 && (d->lda % 8) == 0 && (d->ldb % 8) == 0 && aligned16(d->A) && aligned16(d->B) &&
       !getenv("MK_GEMM_NO_SKINNY")) {
     // cfg 12 = 32 weight rows per workgroup (8 waves), 17 / 18 = 16 rows per workgroup with 8 / 16
     // waves splitting K (measured cold, scripts/gemm_shapes_decode.txt: 4.0 ... 5.7 TB/s against
     // 2.1 ... 3.8; 16 waves where N / 16 workgroups alone would leave a CU with one short wave set)
-    int sk = d->M <= 16 ? ((d->N <= 16 * 256 && d->K <= 4096) ? 18 : 17) : 12;
-    if (g_force_cfg >= 12 && g_force_cfg <= 18 && (g_force_cfg == 12 || d->M <= 16)) sk = g_force_cfg;
+    int sk = d->M <= 16 ? ((d->N <= 16 * 256 && d->K <= 4096) ? 18 : 17) : 19;
+    if (g_force_cfg >= 12 && g_force_cfg <= 19 && (g_force_cfg == 12 || g_force_cfg == 19 || d->M <= 16)) sk = g_force_cfg;
     mkp::set_cfg(prof, sk);
     const dim3 g16(mk_cdiv(d->N, 16));
-    if (sk == 17) MK_LAUNCH((gemm_skinny16_kernel<8, 2, 0, 3>), g16, dim3(512), 0, st, g);
+    if (sk == 19) MK_LAUNCH((gemm_skinny16_kernel<8, 2, 0, 2, 2>), g16, dim3(512), 0, st, g);   // 17 ... 32 token rows
+    else if (sk == 17) MK_LAUNCH((gemm_skinny16_kernel<8, 2, 0, 3>), g16, dim3(512), 0, st, g);
     else if (sk == 18) MK_LAUNCH((gemm_skinny16_kernel<16, 2, 0>), g16, dim3(1024), 0, st, g);
     else if (sk == 13) MK_LAUNCH((gemm_skinny16_kernel<8, 2, 0, 2>), g16, dim3(512), 0, st, g);
     else MK_LAUNCH((gemm_skinny_kernel<8>), dim3(mk_cdiv(d->N, 32)), dim3(512), 0, st, g);

@@ -446,7 +446,7 @@ def decode_linear(x, W, prologue=0, norm_w=None, eps=0.0, residual=None, out=Non
 def decode_linear_ok(x, W, prologue=0):
     """mk_decode_linear's domain; with a prologue the prepared token rows must fit 40 KiB of LDS"""
     M, K = x.shape[0], W.shape[1]
-    return (x.dtype == torch.bfloat16 and M <= 16 and K % 64 == 0 and W.is_contiguous()
+    return (x.dtype == torch.bfloat16 and M <= (16 if prologue else 32) and K % 64 == 0 and W.is_contiguous()
             and (prologue == 0 or M * (K + 8) * 2 <= 40 * 1024))
 
 

@@ -553,7 +553,7 @@ def test_flash_attention_bwd(dev, hd, Lq, Lk, causal, masked):
 
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 22016, 4096), (32, 4096, 11008), (5, 107, 128),
                                    (2, 32007, 4096), (31, 250, 192), (16, 4096, 11008), (7, 4000, 1024),
-                                   (13, 520, 704)])
+                                   (13, 520, 704), (17, 4096, 4096), (24, 1000, 1024)])
 def test_gemm_skinny_decode_rows(dev, M, N, K):
     """M <= 32 (one decode position per sample): the weight-streaming kernel (W rows as the MFMA M
     dimension, split-K across the waves of a workgroup) with every epilogue option, against fp32
