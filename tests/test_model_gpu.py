@@ -201,6 +201,16 @@ def test_generate_hipgraph_decode_matches_eager_loop(dev):
     e = model.llm.generate(inputs_embeds=emb, max_new_tokens=24, eos_token_id=eos, pad_token_id=106,
                            decode_graph=False)
     assert g.shape == e.shape and (g == e).float().mean().item() >= 0.9
+    # unfused q / k / v and gate / up storage: the graph path takes the separate projections
+    mu = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=False).eval()
+    g = mu.llm.generate(inputs_embeds=emb, max_new_tokens=16, eos_token_id=-1, pad_token_id=106)
+    e = mu.llm.generate(inputs_embeds=emb, max_new_tokens=16, eos_token_id=-1, pad_token_id=106, decode_graph=False)
+    assert g.shape == e.shape and (g == e).float().mean().item() >= 0.9
+    # max_new_tokens 1 / 2 / 3 (eager token 0, eager token 1, first replay)
+    for n in (1, 2, 3):
+        g = model.llm.generate(inputs_embeds=emb, max_new_tokens=n, eos_token_id=-1, pad_token_id=106)
+        e = model.llm.generate(inputs_embeds=emb, max_new_tokens=n, eos_token_id=-1, pad_token_id=106, decode_graph=False)
+        assert g.shape == e.shape == (emb.shape[0], n) and (g == e).float().mean().item() >= 0.9
     # and in fp32 parameters (no fused decode attention: the graph path must step aside)
     m32 = build_model(cfg, fx["state"], torch.float32, dev).eval()
     ids = m32.llm.generate(inputs_embeds=fx["inputs_embeds"].to(dev), max_new_tokens=8, eos_token_id=2,
