@@ -298,7 +298,22 @@ def main():
     B = spec["batch"]
     inputs = synthetic_inputs(cfg, B, spec["text_len"], modalities=spec["modalities"], seed=1 + rank, device=dev)
 
-    def step():
+    # MACAW_STEP_GRAPH=1 (N = 1): the whole step (zero grads, forward, backward, fused AdamW) is
+    # captured ONCE in a hipGraph and replayed (macaw_llm_amd.train.GraphedStep: bit-identical to the
+    # eager step, the optimizer scalars and the dropout seed offset live in device memory); the
+    # setup step and the LAST timed step run eagerly, the latter because the per-launch HIP events
+    # behind `roofline` cannot be recorded inside a replay.  Measured 249.1 vs 249.6 ms per step: the
+    # 7 ms of inter-kernel gaps in the rocprofv3 traces are the tracer's, not the eager step's --
+    # hence off by default.
+    graphed = None
+    if not bucketed and os.environ.get("MACAW_STEP_GRAPH") and not os.environ.get("MACAW_OVERLAP_ADAMW"):
+        from macaw_llm_amd.train import GraphedStep
+        runtime.remove()
+        graphed = GraphedStep(model, lambda: model(inputs=inputs).loss, params, opt)
+
+    def step(eager=False):
+        if graphed is not None:
+            return graphed.eager_step() if eager else graphed.step()
         runtime.begin()                      # zero grads, advance Adam's step counter
         loss = model(inputs=inputs).loss
         loss.backward()                      # hooks: all-reduce (N>1) + AdamW behind the backward
@@ -337,9 +352,10 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i == args.steps - 1:
+        last = i == args.steps - 1
+        if last:
             ops.prof_begin()
-        loss = step()
+        loss = step(eager=last)
     fence()
     dt = time.perf_counter() - t0
     if os.environ.get("MACAW_GEMM_REPORT") and rank == 0:
@@ -378,6 +394,9 @@ def main():
                        "parallelism": f"dp{world}" + (": " + runtime.describe() if bucketed else "")
                                       + (f": DEGRADED to per-tensor all-reduce + replicated AdamW (bucketed ZeRO-1 step "
                                          f"failed: {degraded})" if degraded else ""),
+                       "step_launch": ("hipGraph replay of the whole step (train.GraphedStep); setup step and the "
+                                       "last timed step eager (per-launch HIP events)") if graphed is not None
+                                      else "eager, kernel by kernel",
                        "setup_steps": 1, "activation_checkpointing": bool(spec["ckpt"]),
                        "peak_mem_gib": round(peak_mem, 1),
                        "loss": round(float(loss.detach()), 4)},

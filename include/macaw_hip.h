@@ -34,7 +34,7 @@ extern "C" {
 #define MK_FP8 3 /* OCP e4m3fn bytes: mk_gemm operands / mk_fp8_quantize output only */
 
 /* library identification: returns MK_ABI_VERSION */
-#define MK_ABI_VERSION 4
+#define MK_ABI_VERSION 5
 int mk_abi_version(void);
 
 /* ------------------------------------------------------------------ GEMM --
@@ -317,6 +317,19 @@ int mk_decode_attn(const void* q, const void* k, const void* v, void* o, const i
 int mk_adamw(void* param, float* master, float* m, float* v, const void* grad, int64_t n,
              float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
              float grad_scale, int32_t dtype, void* stream);
+
+/* A whole training step replayed from a hipGraph (macaw_llm_amd.train.GraphedStep) cannot change
+ * kernel ARGUMENTS between steps; the two per-step scalars of the path live in device memory:
+ *  - mk_adamw_multi_dev: mk_adamw_multi with hyper_dev = {lr, 1 - beta1^step, 1 - beta2^step,
+ *    grad_scale} (device, f32[4]); mk_adamw_bias_correction fills the two corrections on the HOST
+ *    with mk_adamw_multi's own arithmetic (bit-identical updates);
+ *  - mk_set_dropout_seed_offset: with a device pointer registered every mk_softmax_fwd / _bwd launch
+ *    adds *dev_ptr to its seed when it executes; NULL (default) switches it off. */
+int mk_adamw_bias_correction(float beta1, float beta2, int32_t step, float* out2);
+int mk_adamw_multi_dev(const void* items, const int64_t* chunk_start, int32_t n_items, int64_t n_chunks,
+                       float beta1, float beta2, float eps, float weight_decay, const float* hyper_dev,
+                       int32_t dtype, void* stream);
+int mk_set_dropout_seed_offset(const uint64_t* dev_ptr);
 
 /* ------------------------------------------------------------------ fp8 --
  * BASELINE cfg 5 ("fp8 MFMA for alignment-attn and QKV GEMMs"): per-tensor scaled OCP e4m3.

@@ -30,8 +30,9 @@ MK_DEV float masked(float s, int k, int klim, const int32_t* km) {
 template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void softmax_fwd_wave_kernel(
     const T* scores, T* probs, T* probs_drop, const int32_t* kmask, long nrows, int heads, int Lq,
-    int Lk, long ld, int causal, float p, uint64_t seed) {
+    int Lk, long ld, int causal, float p, uint64_t seed, const uint64_t* seed_dev) {
   constexpr int N = VecIO<T>::N;
+  if (seed_dev) seed += *seed_dev;       // step offset in device memory (mk_set_dropout_seed_offset)
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nrows) return;
@@ -98,7 +99,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_wave_kernel(
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_fwd_block_kernel(
     const T* scores, T* probs, T* probs_drop, const int32_t* kmask, int heads, int Lq, int Lk,
-    long ld, int causal, float p, uint64_t seed) {
+    long ld, int causal, float p, uint64_t seed, const uint64_t* seed_dev) {
+  if (seed_dev) seed += *seed_dev;
   constexpr int N = VecIO<T>::N;
   __shared__ float red[16];
   const long row = blockIdx.x;
@@ -154,7 +156,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_block_kernel(
 template <typename T, int MAXC, bool WAVE>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* probs, T* dprobs, int Lk,
                                                           long ld, float scale, float p,
-                                                          uint64_t seed, long nrows) {
+                                                          uint64_t seed, long nrows, const uint64_t* seed_dev) {
+  if (seed_dev) seed += *seed_dev;
   constexpr int N = VecIO<T>::N;
   __shared__ float red[16];
   const uint32_t thr = keep_thr(p);
@@ -397,7 +400,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamItem* items, const long* chunk_start,
                                                           int n_items, float lr, float b1, float b2,
                                                           float eps, float wd, float bc1, float bc2,
-                                                          float gscale) {
+                                                          float gscale, const float* hyper) {
+  if (hyper) {                              // (lr, bc1, bc2, grad_scale) of THIS step, device memory
+    lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; gscale = hyper[3];
+  }
   int lo = 0, hi = n_items;                 // last item whose first chunk <= blockIdx.x
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -474,6 +480,15 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamItem* items,
 
 #define MK_ST reinterpret_cast<hipStream_t>(stream)
 
+namespace { const uint64_t* g_seed_dev = nullptr; }
+// Training steps replayed from a hipGraph cannot change the seed ARGUMENT of the dropout kernels:
+// with a device pointer registered here every mk_softmax_fwd / mk_softmax_bwd launch adds *ptr to
+// its seed when it executes (the graph advances the value once per step).  NULL switches it off.
+extern "C" int mk_set_dropout_seed_offset(const uint64_t* dev_ptr) {
+  g_seed_dev = dev_ptr;
+  return MK_OK;
+}
+
 namespace {
 template <typename T>
 int softmax_fwd_t(const void* scores, void* probs, void* probs_drop, const int32_t* kmask,
@@ -486,7 +501,7 @@ int softmax_fwd_t(const void* scores, void* probs, void* probs_drop, const int32
     dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
 #define MK_SW(E)                                                                               \
   MK_LAUNCH((softmax_fwd_wave_kernel<T, E>), grid, block, 0, st, (const T*)scores, (T*)probs,   \
-            (T*)probs_drop, kmask, nrows, heads, Lq, Lk, ld, causal, p, seed)
+            (T*)probs_drop, kmask, nrows, heads, Lq, Lk, ld, causal, p, seed, g_seed_dev)
     if (nch <= 64) MK_SW(1);
     else if (nch <= 128) MK_SW(2);
     else if (nch <= 256) MK_SW(4);
@@ -495,7 +510,7 @@ int softmax_fwd_t(const void* scores, void* probs, void* probs_drop, const int32
   } else {
     MK_LAUNCH((softmax_fwd_block_kernel<T>), dim3((unsigned)nrows), dim3(256), 0, st,
               (const T*)scores, (T*)probs, (T*)probs_drop, kmask, heads, Lq, Lk, ld, causal, p,
-              seed);
+              seed, g_seed_dev);
   }
   return mk_check_launch();
 }
@@ -509,14 +524,14 @@ int softmax_bwd_t(const void* probs, void* dprobs, int nz, int Lq, int Lk, long 
     dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
 #define MK_SB(E)                                                                               \
   MK_LAUNCH((softmax_bwd_kernel<T, E, true>), grid, block, 0, st, (const T*)probs, (T*)dprobs,  \
-            Lk, ld, scale, p, seed, nrows)
+            Lk, ld, scale, p, seed, nrows, g_seed_dev)
     if (nch <= 64) MK_SB(1);
     else if (nch <= 128) MK_SB(2);
     else MK_SB(4);
 #undef MK_SB
   } else {
     MK_LAUNCH((softmax_bwd_kernel<T, 1, false>), dim3((unsigned)nrows), dim3(256), 0, st,
-              (const T*)probs, (T*)dprobs, Lk, ld, scale, p, seed, nrows);
+              (const T*)probs, (T*)dprobs, Lk, ld, scale, p, seed, nrows, g_seed_dev);
   }
   return mk_check_launch();
 }
@@ -646,10 +661,38 @@ extern "C" int mk_adamw_multi(const void* items, const int64_t* chunk_start, int
   const long* cs = reinterpret_cast<const long*>(chunk_start);
   if (dtype == MK_BF16)
     MK_LAUNCH((adamw_multi_kernel<bf16>), grid, block, 0, MK_ST, it, cs, n_items, lr, beta1, beta2, eps,
-              weight_decay, bc1, bc2, grad_scale);
+              weight_decay, bc1, bc2, grad_scale, (const float*)nullptr);
   else if (dtype == MK_F32)
     MK_LAUNCH((adamw_multi_kernel<float>), grid, block, 0, MK_ST, it, cs, n_items, lr, beta1, beta2, eps,
-              weight_decay, bc1, bc2, grad_scale);
+              weight_decay, bc1, bc2, grad_scale, (const float*)nullptr);
+  else return MK_ERR_UNSUPPORTED;
+  return mk_check_launch();
+}
+
+// mk_adamw_multi with the per-step scalars in DEVICE memory: hyper_dev = {lr, 1 - beta1^step,
+// 1 - beta2^step, grad_scale}, so a captured launch (hipGraph replay of a training step) follows the
+// learning-rate schedule and the bias correction.  mk_adamw_bias_correction computes the two
+// corrections with the arithmetic mk_adamw_multi uses on the host (bit-identical updates).
+extern "C" int mk_adamw_bias_correction(float beta1, float beta2, int32_t step, float* out2) {
+  if (!out2 || step < 1) return MK_ERR_BAD_ARG;
+  out2[0] = 1.f - powf(beta1, (float)step);
+  out2[1] = 1.f - powf(beta2, (float)step);
+  return MK_OK;
+}
+extern "C" int mk_adamw_multi_dev(const void* items, const int64_t* chunk_start, int32_t n_items,
+                                  int64_t n_chunks, float beta1, float beta2, float eps,
+                                  float weight_decay, const float* hyper_dev, int32_t dtype,
+                                  void* stream) {
+  if (!items || !chunk_start || !hyper_dev || n_items <= 0 || n_chunks <= 0) return MK_ERR_BAD_ARG;
+  const dim3 grid((unsigned)n_chunks), block(256);
+  const AdamItem* it = reinterpret_cast<const AdamItem*>(items);
+  const long* cs = reinterpret_cast<const long*>(chunk_start);
+  if (dtype == MK_BF16)
+    MK_LAUNCH((adamw_multi_kernel<bf16>), grid, block, 0, MK_ST, it, cs, n_items, 0.f, beta1, beta2, eps,
+              weight_decay, 1.f, 1.f, 1.f, hyper_dev);
+  else if (dtype == MK_F32)
+    MK_LAUNCH((adamw_multi_kernel<float>), grid, block, 0, MK_ST, it, cs, n_items, 0.f, beta1, beta2, eps,
+              weight_decay, 1.f, 1.f, 1.f, hyper_dev);
   else return MK_ERR_UNSUPPORTED;
   return mk_check_launch();
 }

@@ -19,7 +19,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libmacaw_hip.so"
 
 MK_F32, MK_BF16, MK_F16, MK_FP8 = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _ERR = {-1: "MK_ERR_BAD_ARG", -2: "MK_ERR_UNSUPPORTED", -3: "MK_ERR_LAUNCH"}
 
@@ -98,6 +98,9 @@ SIGNATURES = {
     "mk_decode_emit": [_vp, _i64, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _vp],
     "mk_decode_step_attn": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i32, _i32,
                             _i32, _i32, _f32, _i32, _vp],
+    "mk_adamw_bias_correction": [_f32, _f32, _i32, _vp],
+    "mk_adamw_multi_dev": [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _f32, _vp, _i32, _vp],
+    "mk_set_dropout_seed_offset": [_vp],
     "mk_kv_append": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _i32, _vp],
     "mk_decode_attn": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64,
                        _i64, _f32, _i32, _vp],

@@ -699,6 +699,14 @@ class MM_LLMs(PreTrainedModel):
         self.dropout_seed = 0x5EED
         self.post_init()
 
+    SEED_STRIDE = 64        # seeds of one step: base + 64 * step + module slot (slot < 64)
+
+    def _dropout_seed(self, slot):
+        """seed of dropout site `slot` in training step self._step.  One stride per step, so a step
+        replayed from a hipGraph gets the same seeds from base + (device counter += SEED_STRIDE)
+        (train.GraphedStep, ops.set_dropout_seed_offset)."""
+        return (self.dropout_seed * 1000003 + self._step * self.SEED_STRIDE + slot) & 0x7FFFFFFFFFFF
+
     # ------------------------------------------------------------ forward ---
     def forward(self, inputs=None):
         _dtype_check(self._param_dtype())
@@ -740,8 +748,7 @@ class MM_LLMs(PreTrainedModel):
         self._step += 1
         p = 0.1 if self.training else 0.0
         meta = dict(ids_full=ids_full, slots=slots, heads=cfg.attention_heads * 2, geom=geom, p=p,
-                    seeds={n: (self.dropout_seed * 1000003 + self._step * 7 + i) & 0x7FFFFFFFFFFF
-                           for i, n in enumerate(eng.MODALITIES)},
+                    seeds={n: self._dropout_seed(i) for i, n in enumerate(eng.MODALITIES)},
                     padding_idx=-1 if self.llm.model.padding_idx is None else self.llm.model.padding_idx)
         params = []
         for name in eng.MODALITIES:
@@ -825,8 +832,7 @@ class MM_LLMs(PreTrainedModel):
         f = eng.AddBroadcastFn.apply(f, pe)
         m = self.video_long_self_attention
         p = m.dropout if self.training else 0.0
-        seed = (self.dropout_seed * 7919 + self._step * 13 + 5) & 0x7FFFFFFFFFFF
-        return eng.MHASelfFn.apply(f, m.num_heads, p, seed, *_mha_params(m))
+        return eng.MHASelfFn.apply(f, m.num_heads, p, self._dropout_seed(40), *_mha_params(m))
 
     def _positional_encoding(self, L, h, dtype, device):
         """create_positional_encoding (modeling.py:1095-1106) is input independent: built once

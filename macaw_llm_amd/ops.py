@@ -408,6 +408,13 @@ def copy2d(src, dst, rows, cols, ld_src, ld_dst, batch=1, s_src=0, s_dst=0, src_
     return dst
 
 
+def set_dropout_seed_offset(t):
+    """register (or, with None, clear) a device int64[1] whose value every dropout kernel adds to
+    its seed at execution time (mk_set_dropout_seed_offset)"""
+    lib = _L.load()
+    _L.check(lib.mk_set_dropout_seed_offset(_p(t) if t is not None else None), "mk_set_dropout_seed_offset")
+
+
 def kv_append(src, cache, cols, batch, s_src, s_cache, ld_cache, t_dev, t_max, src_off=0, dst_off=0):
     """cache[b, *t_dev, dst_off : dst_off + cols] = src[b, src_off : src_off + cols]; the row index is
     read from the DEVICE int32 t_dev at execution time (graph-capturable decode step)"""

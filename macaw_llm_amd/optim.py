@@ -140,6 +140,66 @@ class FusedAdamW:
             t = tabs[dev] = torch.empty(max(need, 4096), dtype=torch.int64, device=dev)
         return t
 
+    # ---- hipGraph form (train.GraphedStep) ------------------------------------------------------
+    def update_hyper(self, device, grad_scale: float = 1.0):
+        """write {lr, 1 - beta1^step, 1 - beta2^step, grad_scale} of the CURRENT step_count to the
+        device buffer the captured optimizer launch reads (stream-ordered H2D from pinned memory)"""
+        import ctypes as C
+        from . import lib as _L
+        if getattr(self, "_hyper_dev", None) is None:
+            self._hyper_dev = torch.zeros(4, dtype=torch.float32, device=device)
+            self._hyper_host = [torch.zeros(4, dtype=torch.float32, pin_memory=True) for _ in range(4)]
+            self._hyper_flip = 0
+        bc = (C.c_float * 2)()
+        _L.check(_L.load().mk_adamw_bias_correction(self.betas[0], self.betas[1], self.step_count, bc),
+                 "mk_adamw_bias_correction")
+        self._hyper_flip = (self._hyper_flip + 1) % len(self._hyper_host)   # (copies of earlier steps in flight)
+        h = self._hyper_host[self._hyper_flip]
+        h[0], h[1], h[2], h[3] = float(self.lr), float(bc[0]), float(bc[1]), float(grad_scale)
+        self._hyper_dev.copy_(h, non_blocking=True)
+
+    def prepare_graph(self, params):
+        """allocations step_params_dev needs, made BEFORE the capture starts (pinned host memory
+        cannot be allocated while a stream is capturing)"""
+        n = len(params)
+        dev = params[0].device
+        self._graph_host = torch.zeros(7 * n + 1, dtype=torch.int64, pin_memory=True)
+        self._graph_dev = torch.zeros(7 * n + 1, dtype=torch.int64, device=dev)
+
+    @torch.no_grad()
+    def step_params_dev(self, params):
+        """step_params for a hipGraph capture: the per-step scalars come from the device buffer of
+        update_hyper(), the pointer table is built ONCE (the captured gradients keep their
+        addresses) and uploaded by a captured copy from pinned memory that stays alive."""
+        from . import lib as _L
+        items = []
+        for p in params:
+            if p.grad is None:
+                continue
+            master, m, v = self._state(p)
+            g = p.grad
+            ptrs = (p.data.data_ptr(), master.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr())
+            if not p.data.is_contiguous() or not g.is_contiguous() or any(x & 15 for x in ptrs):
+                raise ValueError("FusedAdamW.step_params_dev: unaligned / strided parameter or gradient "
+                                 "(use the eager step for this model)")
+            if p.dtype != params[0].dtype or p.device != params[0].device:
+                raise ValueError("FusedAdamW.step_params_dev: one dtype and one device per graph")
+            items.append(ptrs + (p.numel(),))
+        n = len(items)
+        flat, starts = [], [0]
+        for it in items:
+            flat.extend(it)
+            starts.append(starts[-1] + (it[5] + self._CHUNK - 1) // self._CHUNK)
+        host, devt = self._graph_host, self._graph_dev
+        host[: 7 * n + 1] = torch.tensor(flat + starts, dtype=torch.int64)
+        devt.copy_(host, non_blocking=True)
+        b1, b2 = self.betas
+        dev = params[0].device
+        _L.check(_L.load().mk_adamw_multi_dev(devt.data_ptr(), devt.data_ptr() + 6 * n * 8, n, starts[-1], b1, b2,
+                                              self.eps, self.weight_decay, self._hyper_dev.data_ptr(),
+                                              ops._DT[params[0].dtype], torch.cuda.current_stream(dev).cuda_stream),
+                 "mk_adamw_multi_dev")
+
     # ---- ZeRO-1 style shard (train.OverlappedStep, world > 1) ---------------------------------
     def _shard_state(self, key, w):
         st = self.state.get(key)
