@@ -56,6 +56,18 @@ template <> MK_DEV _Float16 from_f32<_Float16>(float v) { return (_Float16)v; }
 // Round-trip through the storage type: the value the eager reference would hold after an
 // op in that dtype.  The bf16 form is done on the bits (RNE) because hipcc folds
 // (float)(__bf16)x back to x under its excess-precision rules.
+// erf(x) to 1.5e-7 absolute (Abramowitz & Stegun 7.1.26: one exp, one reciprocal, five FMAs) for the
+// exact GELU of the Whisper MLPs: libm's erff costs ~4x as many instructions, and the GELU epilogue of
+// 48000 x 2048 outputs was VALU-bound on it.  The result feeds a value that is rounded to bf16
+// (2^-9): the difference to erff is three orders of magnitude below that.
+MK_DEV float mk_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.0f - poly * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+
 template <typename T> MK_DEV float rnd(float v);
 template <> MK_DEV float rnd<float>(float v) { return v; }
 template <> MK_DEV float rnd<bf16>(float v) {

@@ -142,13 +142,13 @@ __global__ __launch_bounds__(256) void swiglu2d_bwd_kernel(const T* g, const T* 
 
 // ------------------------------------------------------------ activations --
 MK_DEV float act_fwd(float v, int act) {
-  if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  if (act == 1) return 0.5f * v * (1.0f + mk_erf(v * 0.70710678118654752440f));
   if (act == 2) return v / (1.0f + __expf(-1.702f * v));
   return v;
 }
 MK_DEV float act_grad(float v, int act) {
   if (act == 1) {
-    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    const float cdf = 0.5f * (1.0f + mk_erf(v * 0.70710678118654752440f));
     const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
     return cdf + v * pdf;
   }

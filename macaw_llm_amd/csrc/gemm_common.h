@@ -29,7 +29,7 @@ struct GemmArgs {
 };
 
 MK_DEV float apply_act(float v, int act) {
-  if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  if (act == 1) return 0.5f * v * (1.0f + mk_erf(v * 0.70710678118654752440f));
   if (act == 2) return v / (1.0f + __expf(-1.702f * v));
   return v;
 }
