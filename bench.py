@@ -65,15 +65,23 @@ CONFIGS = {
 }
 
 
-def pmc_gemm_traffic():
-    """HBM-side bytes per mk_gemm launch from the committed rocprofv3 --pmc passes of this same
-    command (profiles/r02_step_traffic_pmc.csv: FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for
-    gfx950, + WRITE_SIZE, separate passes, last step).  PMC cannot be collected inside a timed run,
-    so the bench line carries the profiled figure; None if the profile is absent."""
+def pmc_gemm_traffic(config: int):
+    """(bytes, source file) -- HBM-side bytes per mk_gemm launch from the committed rocprofv3 --pmc
+    passes of this same command FOR THIS CONFIGURATION (profiles/rNN_step_traffic_pmc[_cfgK].csv:
+    FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE, separate passes, last
+    step).  PMC cannot be collected inside a timed run, so the bench line carries the profiled
+    figure; (None, None) when no PMC profile of this configuration has been committed -- a number
+    measured on another configuration is never substituted."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = os.path.join(here, "r02_step_traffic_pmc.csv")
-    if not os.path.exists(path):
-        path = os.path.join(here, "r01_step_traffic_pmc.csv")
+    suffix = "" if config == 3 else f"_cfg{config}"
+    path = None
+    for rnd in ("r03", "r02", "r01"):
+        cand = os.path.join(here, f"{rnd}_step_traffic_pmc{suffix}.csv")
+        if os.path.exists(cand):
+            path = cand
+            break
+    if path is None:
+        return None, None
     try:
         gb, n = 0.0, 0
         with open(path) as f:
@@ -83,9 +91,9 @@ def pmc_gemm_traffic():
                     # the template argument list contains commas: the numeric columns are the last four
                     n += int(c[-4])
                     gb += float(c[-3]) + float(c[-2])
-        return round(gb * 1e9 / n) if n else None
+        return (round(gb * 1e9 / n), os.path.basename(path)) if n else (None, None)
     except (OSError, ValueError, IndexError):
-        return None
+        return None, None
 
 
 def cpu_baseline(threads: int, spec: dict) -> dict:
@@ -248,19 +256,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MACAW_SHARE_GPU=1 + MACAW_DIST_BACKEND=gloo: N ranks on ONE GPU with gloo collectives -- how the
+    # N > 1 branch of this file is exercised on a 1-GPU box (tests/test_train_gpu.py); never a benchmark
+    share_gpu = bool(os.environ.get("MACAW_SHARE_GPU"))
+    backend = os.environ.get("MACAW_DIST_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     force_coll = bool(os.environ.get("MACAW_FORCE_COLLECTIVES"))   # 1-rank RCCL group: call-path check
     if world > 1 or force_coll:
+        kw = dict(device_id=dev) if backend == "nccl" else {}
         if force_coll and world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
-            dist.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
+            dist.init_process_group(backend=backend, rank=0, world_size=1, **kw)
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend=backend, **kw)
 
     from macaw_llm_amd import ops
-    from macaw_llm_amd.train import OverlappedStep
+    from macaw_llm_amd.bucketed import BucketedStep
     from macaw_llm_amd.factory import baseline_config, build_model, synthetic_inputs
     from macaw_llm_amd.optim import FusedAdamW
 
@@ -280,21 +294,18 @@ def main():
     if spec["ckpt"]:
         model.llm.model.gradient_checkpointing = True     # modeling.py:474-489
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = FusedAdamW(params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
-    # N > 1: flat-bucket ZeRO-1 (macaw_llm_amd/bucketed.py: one reduce-scatter + one all-gather per
-    # ~768 MiB bucket behind the backward).  N = 1: the per-tensor step (no collectives, one
-    # multi-tensor AdamW launch); MACAW_BUCKETED=1 / MACAW_FORCE_COLLECTIVES=1 run the bucketed
-    # path on one GPU (the latter through a 1-rank RCCL group: software overhead of the N > 1 path)
-    bucketed = world > 1 or force_coll or bool(os.environ.get("MACAW_BUCKETED"))
-    if bucketed:
-        from macaw_llm_amd.bucketed import BucketedStep
-        runtime = BucketedStep(params, opt, overlap=not os.environ.get("MACAW_NO_OVERLAP"),
-                               force_collectives=force_coll,
-                               bucket_bytes=int(os.environ.get("MACAW_BUCKET_MB", "768")) << 20)
-    else:
-        runtime = OverlappedStep(params, opt, overlap=not os.environ.get("MACAW_NO_OVERLAP"),
-                                 overlap_optimizer=bool(os.environ.get("MACAW_OVERLAP_ADAMW")),
-                                 shard_optimizer=False, force_collectives=False)
+
+    # ONE step runtime at every N (macaw_llm_amd/bucketed.py): flat buckets; N > 1 = ZeRO-1 (one
+    # reduce-scatter + shard AdamW + one all-gather per ~768 MiB bucket behind the backward, fixed
+    # rank-invariant order), N = 1 = the same buckets with one fused AdamW launch and no collectives.
+    # MACAW_FORCE_COLLECTIVES=1 runs the collective path through a 1-rank RCCL group.
+    def make_runtime(zero1=True):
+        o = FusedAdamW(params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+        return BucketedStep(params, o, model=model, overlap=not os.environ.get("MACAW_NO_OVERLAP"),
+                            force_collectives=force_coll, zero1=zero1,
+                            bucket_bytes=int(os.environ.get("MACAW_BUCKET_MB", "768")) << 20)
+
+    runtime = make_runtime()
     B = spec["batch"]
     inputs = synthetic_inputs(cfg, B, spec["text_len"], modalities=spec["modalities"], seed=1 + rank, device=dev)
 
@@ -306,18 +317,17 @@ def main():
     # 7 ms of inter-kernel gaps in the rocprofv3 traces are the tracer's, not the eager step's --
     # hence off by default.
     graphed = None
-    if not bucketed and os.environ.get("MACAW_STEP_GRAPH") and not os.environ.get("MACAW_OVERLAP_ADAMW"):
+    if world == 1 and not force_coll and os.environ.get("MACAW_STEP_GRAPH"):
         from macaw_llm_amd.train import GraphedStep
-        runtime.remove()
-        graphed = GraphedStep(model, lambda: model(inputs=inputs).loss, params, opt)
+        graphed = GraphedStep(model, lambda: model(inputs=inputs).loss, runtime)
 
     def step(eager=False):
         if graphed is not None:
             return graphed.eager_step() if eager else graphed.step()
         runtime.begin()                      # zero grads, advance Adam's step counter
         loss = model(inputs=inputs).loss
-        loss.backward()                      # hooks: all-reduce (N>1) + AdamW behind the backward
-        runtime.finish()                     # small tensors, join streams
+        loss.backward()                      # hooks: bucket collectives + shard AdamW behind the backward (N > 1)
+        runtime.finish()                     # remaining buckets, the fused AdamW launch (N = 1), stream joins
         return loss
 
     def fence():
@@ -326,25 +336,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # one untimed SETUP step: materialises the optimizer state (fp32 master / m / v, 84 GB at 7B)
-    # and the allocator pools, like building the model.  The W warm-up steps follow.
-    # N > 1: the bucketed ZeRO-1 collectives are the one path a 1-GPU pool cannot run for real.  If
-    # the setup step raises, the run continues on plain all-reduce + replicated AdamW and SAYS SO in
-    # `config.parallelism` (a degraded run must not pass as ZeRO-1; a failure at N = 1 is an error).
+    # one untimed SETUP step: materialises the optimizer state (fp32 master / m / v, 84 GB at 7B),
+    # the allocator pools and the frozen bucket order, like building the model.  The W warm-up steps
+    # follow.  N > 1: the ZeRO-1 collectives are the one path a 1-GPU pool cannot run on real RCCL.
+    # If the setup step raises on ANY rank, ALL ranks agree on it (the verdict travels through a
+    # gloo side group, which does not depend on the state of the RCCL communicator) and continue
+    # together on all-reduce + replicated AdamW (zero1=False), and the line SAYS SO in
+    # `config.parallelism`: a degraded run must not pass as ZeRO-1; a failure at N = 1 is an error.
     degraded = None
+    side_group = dist.new_group(backend="gloo") if (world > 1 and dist.get_backend() != "gloo") else None
+    err = None
+    inject = os.environ.get("MACAW_BENCH_INJECT_FAIL")     # test hook: "<rank>" fails that rank's setup step
     try:
+        if inject is not None and int(inject) == rank:
+            raise RuntimeError("injected setup-step failure (MACAW_BENCH_INJECT_FAIL)")
         step()
-    except Exception as e:
-        if not (world > 1 and bucketed):
+        torch.cuda.synchronize()
+    except Exception as e:       # noqa: BLE001
+        if world == 1:
             raise
-        degraded = repr(e)[:300]
-        print(f"[bench] rank {rank}: bucketed step failed ({degraded}); continuing on all-reduce + replicated "
-              "AdamW (recorded in config.parallelism)", file=sys.stderr, flush=True)
-        runtime.remove()
-        opt = FusedAdamW(params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
-        runtime = OverlappedStep(params, opt, overlap=not os.environ.get("MACAW_NO_OVERLAP"), shard_optimizer=False)
-        bucketed = False
-        step()
+        err = repr(e)[:300]
+    if world > 1:
+        flag = torch.tensor([1 if err else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=side_group)
+        if int(flag.item()):
+            degraded = err or "the setup step failed on another rank"
+            print(f"[bench] rank {rank}: ZeRO-1 setup step failed ({degraded}); all ranks continue on all-reduce + "
+                  "replicated AdamW (recorded in config.parallelism)", file=sys.stderr, flush=True)
+            runtime.remove()
+            runtime = make_runtime(zero1=False)
+            step()
     for _ in range(args.warmup):
         l0 = step()
         if os.environ.get("MACAW_BENCH_VERBOSE") and rank == 0:
@@ -373,6 +394,7 @@ def main():
     if rank == 0:
         S = spec["seq"]
         alg_tf = spec["alg_tf"]
+        traffic, traffic_src = pmc_gemm_traffic(args.config)
         achieved = gemm_flops / (gemm_ms * 1e-3) if gemm_ms > 0 else 0.0
 
         def rate(t):      # (ms, flops, launches) -> dict
@@ -391,9 +413,8 @@ def main():
                                     "run_clm_llms.py:390-393, alignment-attention dropout on"),
                        "baseline_config": args.config,
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": S,
-                       "parallelism": f"dp{world}" + (": " + runtime.describe() if bucketed else "")
-                                      + (f": DEGRADED to per-tensor all-reduce + replicated AdamW (bucketed ZeRO-1 step "
-                                         f"failed: {degraded})" if degraded else ""),
+                       "parallelism": f"dp{world}: " + runtime.describe()
+                                      + (f": DEGRADED from ZeRO-1 (its setup step failed: {degraded})" if degraded else ""),
                        "step_launch": ("hipGraph replay of the whole step (train.GraphedStep); setup step and the "
                                        "last timed step eager (per-launch HIP events)") if graphed is not None
                                       else "eager, kernel by kernel",
@@ -404,9 +425,10 @@ def main():
                                                     "csrc/gemm_v7.hip) + gemm_bf16_v2_kernel (128x128, csrc/gemm.hip)",
                          "achieved": round(achieved / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK, 4),
-                         "traffic": pmc_gemm_traffic(),
-                         "traffic_note": "HBM-side bytes per mk_gemm launch of the cfg 3 step (rocprofv3 PMC, "
-                                         "profiles/r02_step_traffic_pmc.csv; includes Infinity-Cache hits)",
+                         "traffic": traffic,
+                         "traffic_note": (f"HBM-side bytes per mk_gemm launch of the cfg {args.config} step (rocprofv3 "
+                                          f"PMC, profiles/{traffic_src}; includes Infinity-Cache hits)") if traffic
+                                         else f"no PMC profile of cfg {args.config} committed under profiles/",
                          "launches_per_step": gemm_n, "gemm_ms_per_step": round(gemm_ms, 3),
                          "gemm_tflop_per_step": round(gemm_flops / 1e12, 2),
                          "whole_step_model_tflops": round(value / world * alg_tf, 1),
@@ -417,6 +439,8 @@ def main():
         }
         if args.layers is not None:
             line["invalid"] = f"debug run with --layers {args.layers}"
+        if share_gpu or backend != "nccl" or inject is not None:
+            line["invalid"] = "call-path test (ranks sharing one GPU / gloo collectives / injected failure), not a benchmark"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb = cpu_baseline(host_cores(), spec)

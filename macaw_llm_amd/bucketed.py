@@ -1,5 +1,7 @@
-"""Bucketed data-parallel training step (one process per GPU, torch.distributed "nccl" = RCCL over
-xGMI; gloo for the CPU tests).
+"""The training-step runtime: flat parameter / gradient buckets, ZeRO-1 over RCCL for N > 1 ranks,
+ONE fused AdamW launch for N = 1 (one process per GPU, torch.distributed "nccl" = RCCL over xGMI;
+gloo for the CPU tests).  Since round 3 this is the only step runtime of the package: bench.py runs
+it at every N (the per-tensor steps of rounds 1-2 live on as test references, tests/legacy_steps.py).
 
 The reference trains under DeepSpeed ZeRO (train.sh:14-16, configs/deepspeed_config.json:22-41:
 fp16 parameter all-gathers and gradient reduce-scatters in `hidden^2`-element buckets, gradient
@@ -9,29 +11,44 @@ accumulation 3, gradient clipping, cosine schedule with 3 % warm-up).  On MI355X
   * at construction every trainable parameter is re-homed into one of a few large flat buffers
     (`bucket_bytes`, default 768 MiB -> ~18 buckets at 7B), ordered so that a bucket fills up in
     backward order; parameters that already sit back to back (fused q|k|v, gate|up) stay in that
-    order.  State-dict keys do not change (the parameters become views, as with
-    LlamaDecoderLayer.fuse_projections).
-  * a second set of flat buffers of the same layout receives the gradients.  The grad-weight GEMMs
-    of the decoder layers and lm_head write STRAIGHT into them (ops.GRAD_DST); any other gradient
-    is copied in by its post-accumulate hook.
-  * when the last gradient of a bucket has arrived, ONE collective goes out for the whole bucket:
-    `reduce_scatter_tensor` into a preallocated shard buffer (each rank receives the mean of its
-    1/N slice over all 7 xGMI links at once), then -- on a side stream, behind the remaining
+    order.  State-dict keys do not change (the parameters become views).  Pass `model=` and the
+    q|k|v / gate|up projections are fused FIRST (modeling.fuse_model); once a parameter lives in a
+    bucket the lazy fusion of modeling.py refuses to move it (ops.PINNED_STORAGE) and begin()
+    verifies every step that each parameter still views its bucket slot.
+  * a second set of flat buffers of the same layout receives the gradients.  The grad-weight GEMMs,
+    the norm-weight / bias reductions and the embedding-table gradient write STRAIGHT into them
+    (ops.GRAD_DST); any other gradient is copied in by its post-accumulate hook.
+  * N > 1: when the last gradient of a bucket has arrived, ONE collective goes out for the whole
+    bucket: `reduce_scatter_tensor` into a preallocated shard buffer (each rank receives the mean of
+    its 1/N slice over all 7 xGMI links at once), then -- on a side stream, behind the remaining
     backward -- fused AdamW on that slice (fp32 master / moments exist only for the slice) and
     `all_gather_into_tensor` of the updated bf16 slice in place into the parameter bucket.
     2 collectives per bucket, <= 40 per step, no allocation inside the step.
+  * RANK-INVARIANT SCHEDULE.  Collectives must be issued in the same order by every rank, whatever
+    gradients each rank's batch produced (a modality absent on one rank leaves that rank's bucket
+    incomplete until the end of its backward).  Buckets therefore go out in ONE fixed order: the
+    first step is a discovery step (nothing is launched during its backward; the order in which
+    rank 0's buckets completed is broadcast and frozen), afterwards bucket k of that order is
+    launched as soon as it AND all its predecessors are complete, the rest in finish().  Every
+    bucket is launched every step; parameters without a gradient contribute zeros (the ZeRO flat
+    partition semantics: their moments decay, weight decay applies).
+  * N = 1: no collectives; finish() updates all buckets with ONE multi-tensor AdamW launch over a
+    static pointer table (FusedAdamW.step_buckets).
   * gradient accumulation: `accumulate_steps` micro-batches add into the gradient buckets; the
-    collectives and the update run on the last one only (DDP's no_sync()).
+    collectives and the update run on the last one only (DDP's no_sync()) and the SUM is divided
+    by accumulate_steps inside AdamW's grad_scale (`average_accumulated`, default on: HF Trainer /
+    DeepSpeed divide the loss by gradient_accumulation_steps, train.sh:29).
   * `max_grad_norm`: global-norm clipping as HF Trainer / DeepSpeed do it: the reduce-scatters still
     overlap the backward, the updates wait for the global norm (sum of the shard norms^2 +
     one scalar all-reduce) and take the clip factor as AdamW's grad_scale.
   * learning-rate schedule: `set_lr()` per step; `cosine_with_warmup()` is HF's
     get_cosine_schedule_with_warmup (train.sh: --lr_scheduler_type cosine --warmup_ratio 0.03).
+  * `zero1=False`: all-reduce of each bucket + replicated update (the plain-DDP form; bench.py's
+    fallback if the ZeRO-1 collectives fail on a machine).
 
-With one rank there are no collectives and a shard is the whole bucket; the arithmetic is the
-same kernel (mk_adamw) on the same values, so N = 1 and N > 1 agree bit for bit on equal
-gradients.  After a step `p.grad` views the LOCAL (unreduced) gradient bucket; the rank-mean
-exists only as shards (use `grad_norm` for the global norm).
+With one rank a shard is the whole bucket; the arithmetic is the same kernel body on the same
+values, so N = 1 and N > 1 agree bit for bit on equal gradients.  After a step `p.grad` views the
+LOCAL (unreduced) gradient bucket; the rank-mean exists only as shards (`grad_norm` = global norm).
 """
 from __future__ import annotations
 
@@ -53,6 +70,15 @@ def cosine_with_warmup(step: int, total_steps: int, warmup_ratio: float = 0.03, 
         return base_lr * step / max(1, warm)
     prog = (step - warm) / max(1, total_steps - warm)
     return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * num_cycles * 2.0 * prog)))
+
+
+def shard_batch(global_batch: int, rank: int, world: int):
+    """Even split of the global batch (train.sh: per_device_train_batch_size x 8 ranks); returns
+    (start, stop) of this rank's samples."""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} not divisible by world size {world}")
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
 
 
 def _dev(t):
@@ -81,7 +107,7 @@ def _zero_(t):
 
 
 class _Bucket:
-    __slots__ = ("idx", "w", "g", "shard_g", "items", "n", "arrived", "launched", "rs", "missing")
+    __slots__ = ("idx", "w", "g", "shard_g", "items", "n", "arrived", "launched", "ready", "rs", "seen", "dirty")
 
     def __init__(self, idx):
         self.idx = idx
@@ -89,17 +115,27 @@ class _Bucket:
         self.n = 0
         self.arrived = 0
         self.launched = False
+        self.ready = False
         self.rs = None
-        self.missing = None
+        self.seen = set()      # ids of the parameters that received a gradient in this window
+        self.dirty = set()     # ids whose gradient slot may be non-zero (written since it was zeroed)
 
 
 class BucketedStep:
     ALIGN = 64                 # elements: every parameter starts 128-byte aligned inside its bucket
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], opt, process_group=None,
+    def __init__(self, params: Optional[Iterable[torch.nn.Parameter]], opt, process_group=None,
                  bucket_bytes: int = 768 << 20, accumulate_steps: int = 1,
                  max_grad_norm: Optional[float] = None, overlap: bool = True,
-                 force_collectives: bool = False, direct_grads: bool = True):
+                 force_collectives: bool = False, direct_grads: bool = True, model=None,
+                 zero1: bool = True, average_accumulated: bool = True):
+        if model is not None:
+            # fuse q|k|v / gate|up BEFORE the parameters are pinned into buckets (the lazy fusion at
+            # the first forward must never re-home a bucket view: round-2 advisor finding)
+            from . import modeling as _m
+            _m.fuse_model(model)
+            if params is None:
+                params = model.parameters()
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -110,14 +146,21 @@ class BucketedStep:
         self.rank = dist.get_rank(process_group) if init else 0
         self._avg = init and dist.get_backend(process_group) == "nccl"   # gloo has no AVG
         self.collective = self.world > 1 or (force_collectives and init)
+        self.zero1 = bool(zero1)
         self.accumulate_steps = max(1, int(accumulate_steps))
+        self.average_accumulated = bool(average_accumulated)
         self.max_grad_norm = max_grad_norm
         self.overlap = overlap
         self.direct_grads = direct_grads
+        self.dev_hyper = False         # True while train.GraphedStep captures: AdamW scalars from device memory
         self.grad_norm = None          # device scalar (fp32) of the last clipped step
         self._micro = 0
+        self._order = None             # frozen launch order (bucket indices); None until the discovery step ran
+        self._cursor = 0
+        self._arrival: List[int] = []
         dev = self.params[0].device
-        self.side = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and overlap) else None
+        self.side = (torch.cuda.Stream(device=dev)
+                     if (dev.type == "cuda" and overlap and self.collective) else None)
         self._build(bucket_bytes)
         self._gathers = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
@@ -190,9 +233,10 @@ class BucketedStep:
                 p.data = b.w[off:off + n].view(p.shape)
             b.n = total
             b.shard_g = (torch.empty(total // self.world, dtype=p0.dtype, device=p0.device)
-                         if self.collective else None)
-        # destinations of the grad-weight GEMMs, keyed (data_ptr, numel): every parameter, and every
-        # fused run of 2-D weights with equal inner dimension under its first member's pointer
+                         if (self.collective and self.zero1) else None)
+            ops.PINNED_STORAGE.add(b.w.untyped_storage().data_ptr())
+        # destinations of the gradient-producing kernels, keyed (data_ptr, numel): every parameter, and
+        # every fused run of 2-D weights with equal inner dimension under its first member's pointer
         self._dst = {}
         for p in self.params:
             bk, off = self._where[p]
@@ -210,6 +254,17 @@ class BucketedStep:
         if on:
             ops.GRAD_DST.update(self._dst)
 
+    def _check_homes(self):
+        """every parameter must still view its bucket slot (something re-materialised it otherwise --
+        .to(), a manual p.data = ..., a fusion pass -- and the optimizer would update a stale copy)"""
+        for b in self.buckets:
+            base, es = b.w.data_ptr(), b.w.element_size()
+            for p, off, n in b.items:
+                if p.data.data_ptr() != base + off * es or p.numel() != n:
+                    raise RuntimeError(
+                        "BucketedStep: a parameter no longer views its bucket slot (it was moved or re-homed "
+                        "after the runtime was built: build BucketedStep AFTER .to() / fusion, or pass model=)")
+
     # --------------------------------------------------------------------- step ---
     def set_lr(self, lr: float):
         self.opt.lr = float(lr)
@@ -219,14 +274,18 @@ class BucketedStep:
         first = self._micro == 0
         if first:
             self.opt.step_count += 1
+            self._check_homes()
             for b in self.buckets:
-                b.arrived, b.launched, b.rs, b.missing = 0, False, None, set()
+                b.arrived, b.launched, b.ready, b.rs = 0, False, False, None
+                b.seen = set()
+            self._cursor = 0
+            self._arrival = []
         else:
             for b in self.buckets:
                 b.arrived = 0
         for p in self.params:
             p.grad = None
-        # straight-into-the-bucket GEMM stores only on the first micro-batch (later ones ADD)
+        # straight-into-the-bucket stores only on the first micro-batch (later ones ADD)
         self._install_dst(first)
 
     def _last_micro(self):
@@ -239,116 +298,185 @@ class BucketedStep:
         b, off = self._where[p]
         n = p.numel()
         dst = b.g[off:off + n]
-        first_time = id(p) not in b.missing      # `missing` doubles as the set of SEEN parameters
+        first_time = id(p) not in b.seen
         if g.data_ptr() != dst.data_ptr():
             src = g if g.is_contiguous() else g.contiguous()
             (_copy_ if first_time else _add_)(dst, src.view(-1))
         elif not first_time:
             raise RuntimeError("gradient written in place on an accumulation micro-step")
-        b.missing.add(id(p))
+        b.seen.add(id(p))
+        b.dirty.add(id(p))
         p.grad = dst.view(p.shape)
         b.arrived += 1
         if b.arrived == len(b.items) and self._last_micro():
+            b.ready = True
+            self._arrival.append(b.idx)
+            self._advance()
+
+    def _advance(self):
+        """launch the longest prefix of the frozen order whose buckets are complete"""
+        if self._order is None:
+            return                     # discovery step: everything goes out in finish()
+        while self._cursor < len(self._order):
+            b = self.buckets[self._order[self._cursor]]
+            if not b.ready:
+                return
             self._launch(b)
+            self._cursor += 1
+
+    def _acc_scale(self) -> float:
+        return 1.0 / self.accumulate_steps if (self.average_accumulated and self.accumulate_steps > 1) else 1.0
 
     def _launch(self, b: _Bucket):
         b.launched = True
         if not self.collective:
             return
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        b.rs = (dist.reduce_scatter_tensor(b.shard_g, b.g, op=op, group=self.group, async_op=self.overlap), False)
+        if self.zero1:
+            h = dist.reduce_scatter_tensor(b.shard_g, b.g, op=op, group=self.group, async_op=self.overlap)
+        else:
+            h = dist.all_reduce(b.g, op=op, group=self.group, async_op=self.overlap)
+        b.rs = (h, False)
         if self.max_grad_norm is None and self.side is not None:
-            b.shard_g.record_stream(self.side)
+            (b.shard_g if self.zero1 else b.g).record_stream(self.side)
             with torch.cuda.stream(self.side):
-                self._finish_bucket(b, 1.0)
+                self._finish_bucket(b, self._acc_scale())
 
     def _shard(self, b):
-        n = b.n // self.world if self.collective else b.n
-        lo = self.rank * n if self.collective else 0
-        return lo, n
+        if self.collective and self.zero1:
+            n = b.n // self.world
+            return self.rank * n, n
+        return 0, b.n
 
     def _reduced(self, b: _Bucket):
-        """the rank-mean gradient of this rank's slice (waits for the reduce-scatter, stream-ordered)"""
+        """the rank-mean gradient of this rank's slice (waits for the collective, stream-ordered)"""
         if not self.collective:
             return b.g
         h, meaned = b.rs
+        out = b.shard_g if self.zero1 else b.g
         if h is not None:
             h.wait()
         if not meaned and not self._avg:
-            b.shard_g.div_(self.world)        # gloo (tests): SUM -> mean
+            out.div_(self.world)              # gloo (tests): SUM -> mean
         b.rs = (None, True)
-        return b.shard_g
+        return out
 
     def _finish_bucket(self, b: _Bucket, scale: float):
         """update the owned slice from the reduced gradient, gather the updated slices in place"""
         lo, n = self._shard(b)
         gs = self._reduced(b)
         self.opt.step_shard((b.idx, lo, n), b.w[lo:lo + n], gs, scale)
-        if self.collective:
+        if self.collective and self.zero1:
             h = dist.all_gather_into_tensor(b.w, b.w[lo:lo + n], group=self.group, async_op=self.overlap)
             if h is not None:
                 self._gathers.append(h)
 
+    def _zero_missing(self, b: _Bucket):
+        """gradient slots of parameters that got no gradient in this window must read as zeros; a slot
+        is re-zeroed only if something was written to it since the last time (never-used parameters
+        cost nothing per step)"""
+        run_lo = run_hi = None
+        for p, off, n in b.items:
+            if id(p) in b.seen or id(p) not in b.dirty:
+                continue
+            b.dirty.discard(id(p))
+            if run_hi == off:                  # coalesce neighbours into one fill
+                run_hi = off + n
+                continue
+            if run_lo is not None:
+                _zero_(b.g[run_lo:run_hi])
+            run_lo, run_hi = off, off + n
+        if run_lo is not None:
+            _zero_(b.g[run_lo:run_hi])
+
+    def _freeze_order(self):
+        nb = len(self.buckets)
+        done = set(self._arrival)
+        order = list(self._arrival) + [i for i in range(nb) if i not in done]
+        if self.collective:
+            dev = self.params[0].device
+            t = torch.tensor(order, dtype=torch.int64, device=dev)
+            src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.broadcast(t, src=src, group=self.group)
+            order = [int(x) for x in t.tolist()]
+        if sorted(order) != list(range(nb)):
+            raise RuntimeError("BucketedStep: inconsistent bucket order across ranks (different models?)")
+        self._order = order
+
     def finish(self):
         """call after the backward of every micro-batch; on the last one of a window it completes
-        the step: buckets whose parameters did not all receive a gradient (an absent modality) are
-        flushed with zeros for the missing ones, the global norm is formed if clipping is on, every
-        update and all-gather is joined."""
+        the step: the remaining buckets go out in the frozen order (zeros for parameters without a
+        gradient), the global norm is formed if clipping is on, every update and all-gather is
+        joined."""
         if not self._last_micro():
             self._micro += 1
             return
         self._micro = 0
         self._install_dst(False)
+        if self._order is None:
+            self._freeze_order()
+        while self._cursor < len(self._order):
+            b = self.buckets[self._order[self._cursor]]
+            self._zero_missing(b)
+            self._launch(b)
+            self._cursor += 1
         queued = self.collective and self.max_grad_norm is None and self.side is not None
-        for b in self.buckets:
-            if not b.launched:
-                if not b.missing:
-                    continue                    # nothing in this bucket was used: no update at all
-                for p, off, n in b.items:
-                    if id(p) not in b.missing:
-                        _zero_(b.g[off:off + n])
-                self._launch(b)
-        active = [b for b in self.buckets if b.launched]
         if not queued:
-            scale = self._clip_scale(active) if self.max_grad_norm is not None else 1.0
-            for b in active:
-                self._finish_bucket(b, scale)
+            scale = self._acc_scale()
+            if self.max_grad_norm is not None:
+                scale = self._clip_scale(scale)
+            if not self.collective and hasattr(self.opt, "step_buckets") and self.buckets[0].w.is_cuda:
+                self.opt.step_buckets([((b.idx, 0, b.n), b.w, b.g) for b in self.buckets], scale,
+                                      dev_hyper=self.dev_hyper)
+            else:
+                for i in self._order:
+                    self._finish_bucket(self.buckets[i], scale)
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
         for h in self._gathers:                 # the next forward reads the gathered parameters
             h.wait()
         self._gathers.clear()
 
-    def _clip_scale(self, active):
-        """grad_scale = min(1, max_norm / (||g|| + 1e-6)) as torch.nn.utils.clip_grad_norm_;
-        ||g|| over the rank-mean gradient = sqrt(sum over ranks of the owned shards' norms^2)"""
+    def _clip_scale(self, acc_scale: float):
+        """grad_scale = acc_scale * min(1, max_norm / (||g|| + 1e-6)) as torch.nn.utils.clip_grad_norm_;
+        ||g|| over the rank-mean (and micro-batch-mean) gradient = acc_scale * sqrt(sum over ranks of
+        the owned shards' norms^2)"""
         dev = self.params[0].device
         tot = torch.zeros(1, dtype=torch.float32, device=dev)
-        for b in active:
-            gs = self._reduced(b)
+        for i in self._order:
+            gs = self._reduced(self.buckets[i])
             if _dev(gs):
                 ops.sumsq(gs, out=tot, accumulate=True)
             else:
                 tot += gs.float().pow(2).sum()
-        if self.collective:
+        if self.collective and self.zero1:
             dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
-        self.grad_norm = tot.sqrt()
+        self.grad_norm = tot.sqrt() * acc_scale
         # the clip factor is a host scalar of AdamW's launch: one small D2H sync per step, as the
         # reference's trainers pay for their overflow / norm checks
-        return min(1.0, float(self.max_grad_norm) / (float(self.grad_norm) + 1e-6))
+        return acc_scale * min(1.0, float(self.max_grad_norm) / (float(self.grad_norm) + 1e-6))
 
     def remove(self):
         for h in self._hooks:
             h.remove()
         self._hooks.clear()
         self._install_dst(False)
+        for b in self.buckets:
+            ops.PINNED_STORAGE.discard(b.w.untyped_storage().data_ptr())
 
     # -------------------------------------------------------------- introspection ---
     def describe(self) -> str:
         nb = len(self.buckets)
         mb = sum(b.n * b.w.element_size() for b in self.buckets) / 2 ** 20
-        mode = "ZeRO-1 reduce-scatter / shard AdamW / all-gather" if self.collective else "local"
+        if not self.collective:
+            mode = "local (one fused AdamW launch)"
+        elif self.zero1:
+            mode = "ZeRO-1 reduce-scatter / shard AdamW / all-gather"
+        else:
+            mode = "all-reduce / replicated AdamW"
+        ncoll = (2 * nb if self.zero1 else nb) if self.collective else 0
         return (f"{nb} flat buckets, {mb:.0f} MiB of parameters, {mode}"
-                + (f", {2 * nb} collectives per step" if self.collective else "")
-                + (f", grad accumulation x{self.accumulate_steps}" if self.accumulate_steps > 1 else "")
+                + (f", {ncoll} collectives per step in a fixed rank-invariant order" if ncoll else "")
+                + (f", grad accumulation x{self.accumulate_steps}"
+                   + (" (mean)" if self.average_accumulated else " (sum)") if self.accumulate_steps > 1 else "")
                 + (f", clip {self.max_grad_norm}" if self.max_grad_norm is not None else ""))

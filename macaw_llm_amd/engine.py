@@ -233,7 +233,7 @@ class LlamaLayerFn(torch.autograd.Function):
             dwg = ops.linear_dw(dg, y2) if need[11] else None
             dwu = ops.linear_dw(du, y2) if need[12] else None
             del dg, du
-        dh1, dln2 = ops.rmsnorm_bwd(dy2, h1, ln2, rstd2, dres=dout2)
+        dh1, dln2 = ops.rmsnorm_bwd(dy2, h1, ln2, rstd2, dres=dout2, dw_out=ops.grad_dst(ln2) if need[15] else None)
         # ---- attention
         datt = ops.linear_dx(dh1, wo)
         dwo = ops.linear_dw(dh1, att, w=wo) if need[10] else None
@@ -270,7 +270,7 @@ class LlamaLayerFn(torch.autograd.Function):
             dwq = ops.linear_dw(dq, y1) if need[7] else None
             dwk = ops.linear_dw(dk, y1) if need[8] else None
             dwv = ops.linear_dw(dv, y1) if need[9] else None
-        dx, dln1 = ops.rmsnorm_bwd(dy1, x2, ln1, rstd1, dres=dh1)
+        dx, dln1 = ops.rmsnorm_bwd(dy1, x2, ln1, rstd1, dres=dh1, dw_out=ops.grad_dst(ln1) if need[14] else None)
         return (dx.view(B, S, D), None, None, None, None, None, None, dwq, dwk, dwv, dwo, dwg, dwu,
                 dwd, dln1 if need[14] else None, dln2 if need[15] else None, None, None, None)
 
@@ -415,7 +415,7 @@ class LMHeadLossFn(torch.autograd.Function):
         # zero-filled): the K = V reduction of dx runs on the tile kernels over the padded width
         dy = ops.linear_dx(dlv, lm_w, dy_pad_zero=True)
         dlm = ops.linear_dw(dlv, y, w=lm_w) if need[2] else None
-        dh, dnw = ops.rmsnorm_bwd(dy, h2, norm_w, rstd)
+        dh, dnw = ops.rmsnorm_bwd(dy, h2, norm_w, rstd, dw_out=ops.grad_dst(norm_w) if need[1] else None)
         return dh.view(B, S, D), (dnw if need[1] else None), dlm, None, None
 
 
@@ -689,7 +689,7 @@ def _align_bwd(da, E, dE, dE_init, prm, saved, dims, need_feats):
     V, D = E.shape
     hd, Lq, Lk = D // H, B * Lout, V + 2
     g = {}
-    g["out_w"], g["out_b"] = ops.linear_dw(da, o), ops.colsum(da)
+    g["out_w"], g["out_b"] = ops.linear_dw(da, o, w=out_w), ops.colsum(da, out=ops.grad_dst(out_b))
     do = ops.linear_dx(da, out_w)
     dq = torch.empty_like(q)
     dkv = torch.empty_like(kv)
@@ -703,22 +703,28 @@ def _align_bwd(da, E, dE, dE_init, prm, saved, dims, need_feats):
     dkvt = dkv[:V]
     # table gradient: dE (+)= dKV W_kv
     ops.linear_dx(dkvt, in_w[D:], out=dE, accumulate=not dE_init)
-    din_w = torch.empty_like(in_w)
-    din_b = torch.empty((3 * D,), dtype=da.dtype, device=da.device)
+    din_w = ops.grad_dst(in_w)              # (a registered gradient-bucket slot, else a fresh tensor)
+    if din_w is None:
+        din_w = torch.empty_like(in_w)
+    din_b = ops.grad_dst(in_b)
+    if din_b is None:
+        din_b = torch.empty((3 * D,), dtype=da.dtype, device=da.device)
     ops.linear_dw(dq, t, out=din_w[:D])
     ops.linear_dw(dkvt, E, out=din_w[D:])
     ops.colsum(dq, out=din_b[:D])
     ops.colsum(dkvt, out=din_b[D:])
     g["in_w"], g["in_b"] = din_w, din_b
     dt = ops.linear_dx(dq, in_w[:D])
-    g["lin_w"], g["lin_b"] = ops.linear_dw(dt, pj), ops.colsum(dt)
+    g["lin_w"], g["lin_b"] = ops.linear_dw(dt, pj, w=lin_w), ops.colsum(dt, out=ops.grad_dst(lin_b))
     dpj = ops.linear_dx(dt, lin_w)
     K = C * kw
     cw = conv_w.view(conv_w.shape[0], K)
-    dcw = torch.empty_like(cw)
+    dcw = ops.grad_dst(cw)
+    if dcw is None:
+        dcw = torch.empty_like(cw)
     ops.gemm_raw(dpj, cols, dcw, cw.shape[0], K, Lq, dpj.stride(0), cols.stride(0), K, a_red=True,
                  b_red=True)
-    g["conv_w"], g["conv_b"] = dcw.view_as(conv_w), ops.colsum(dpj)
+    g["conv_w"], g["conv_b"] = dcw.view_as(conv_w), ops.colsum(dpj, out=ops.grad_dst(conv_b))
     dfeats = None
     if need_feats:
         dcols = torch.empty((Lq, cols.shape[1]), dtype=da.dtype, device=da.device)
@@ -771,7 +777,9 @@ class PrefixAssembleFn(torch.autograd.Function):
         V, D = E.shape
         need = ctx.needs_input_grad
         dout2 = _c2(dout, B * S, D)
-        dE = torch.empty_like(E)
+        dE = ops.grad_dst(E) if need[0] else None     # straight into the gradient bucket when one is registered
+        if dE is None:
+            dE = torch.empty_like(E)
         dE_init = True
         grads = [None] * (len(MODALITIES) * N_ALIGN_PARAMS)
         dfeats = dict(image=None, audio=None, video=None)

@@ -73,9 +73,23 @@ def _rows_view(ts):
         return None
 
 
+_PIN_WARNED = [False]
+
+
 @torch.no_grad()
 def _rehome_rows(ts):
-    """concatenate along dim 0 into one new buffer and make every tensor a view of it"""
+    """concatenate along dim 0 into one new buffer and make every tensor a view of it.  Refused
+    (returns None) for parameters that live in a BucketedStep's flat buckets: moving them would
+    leave the optimizer and the collectives updating the bucket while the model computes with the
+    copy (build the runtime with model= / call fuse_model() first to get the fused GEMMs)."""
+    if any(ops.is_pinned(t.data) for t in ts):
+        if not _PIN_WARNED[0]:
+            _PIN_WARNED[0] = True
+            import warnings
+            warnings.warn("macaw_llm_amd: q|k|v / gate|up parameters already live in BucketedStep buckets and "
+                          "were not fused; the layer runs one GEMM per projection (correct, slower).  Pass "
+                          "model= to BucketedStep or call modeling.fuse_model(model) before building it.")
+        return None
     fused = torch.cat([t.data for t in ts], dim=0).contiguous()
     off = 0
     for t in ts:
@@ -111,8 +125,11 @@ def fused_encoder_qkv(attn):
         return None, None
     with torch.no_grad():
         if W3 is None:
-            _rehome_rows(ws)
+            if _rehome_rows(ws) is None:
+                return None, None
             W3 = _rows_view(ws)
+        if any(lin.bias is not None and ops.is_pinned(lin.bias.data) for lin in (q, k, v)):
+            return None, None          # biases pinned in an optimizer bucket: keep the per-projection GEMMs
         b3 = torch.empty(3 * E, dtype=q.weight.dtype, device=q.weight.device)
         ops.fill_(b3, 0.0)
         for i, lin in enumerate((q, k, v)):
@@ -121,6 +138,20 @@ def fused_encoder_qkv(attn):
                 lin.bias.data = b3[i * E:(i + 1) * E]
         attn._macaw_b3 = b3
     return W3, b3
+
+
+def fuse_model(model):
+    """fuse every q|k|v / gate|up projection of `model` NOW (decoder layers, and the CLIP / Whisper
+    attention modules when they are on the device) instead of lazily at the first forward.  Call it
+    -- or pass model= to bucketed.BucketedStep -- before parameters are handed to an optimizer
+    runtime that re-homes them.  Idempotent."""
+    for mod in model.modules():
+        if isinstance(mod, LlamaDecoderLayer):
+            mod.fuse_projections()
+        elif (all(hasattr(mod, n) for n in ("q_proj", "k_proj", "v_proj", "out_proj"))
+              and isinstance(getattr(mod, "q_proj"), nn.Linear) and mod.q_proj.weight.is_cuda):
+            fused_encoder_qkv(mod)
+    return model
 
 
 # ---------------------------------------------------------------- LLaMA -----

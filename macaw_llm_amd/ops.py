@@ -177,14 +177,27 @@ def linear_dx(dy, W, out=None, accumulate=False, residual=None, dy_pad_zero=Fals
 # gradient allocation).  Empty = every dW gets a fresh tensor (the default).
 GRAD_DST = {}
 
+# data_ptr of every storage that a BucketedStep owns (parameter buckets).  Parameters living there
+# must never be re-homed by the lazy q|k|v / gate|up fusion of modeling.py: the optimizer and the
+# collectives keep working on the bucket, the model would compute with the moved copy.
+PINNED_STORAGE = set()
+
+
+def is_pinned(t) -> bool:
+    """True if tensor `t` views a storage owned by a BucketedStep"""
+    return bool(PINNED_STORAGE) and t.untyped_storage().data_ptr() in PINNED_STORAGE
+
 
 def grad_dst(w):
-    """registered destination for dW of weight `w` (same shape), else None"""
+    """registered destination for the gradient of parameter `w` (same shape), else None"""
     if not GRAD_DST or w is None:
         return None
     d = GRAD_DST.get((w.data_ptr(), w.numel()))
-    if d is not None and d.shape == w.shape and d.dtype == w.dtype:
-        return d
+    if d is not None and d.dtype == w.dtype:
+        if d.shape == w.shape:
+            return d
+        if d.numel() == w.numel() and w.is_contiguous():
+            return d.view(w.shape)
     return None
 
 

@@ -140,23 +140,73 @@ class FusedAdamW:
             t = tabs[dev] = torch.empty(max(need, 4096), dtype=torch.int64, device=dev)
         return t
 
+    # ---- flat buckets (bucketed.BucketedStep, one rank) -----------------------------------------
+    @torch.no_grad()
+    def step_buckets(self, items, grad_scale: float = 1.0, dev_hyper: bool = False):
+        """update every flat bucket with ONE launch.  items: [(key, w, g)] with w / g the whole flat
+        parameter / gradient buffer of a bucket (fixed addresses), key as in step_shard.  The
+        pointer table is STATIC: built and uploaded once per set of buckets, so a step costs one
+        launch and no host-to-device traffic (dev_hyper: the per-step scalars come from the device
+        buffer of update_hyper(), for graph capture)."""
+        from . import lib as _L
+        ck = tuple(k for k, _, _ in items)
+        cache = self.__dict__.setdefault("_bucket_tables", {})
+        ent = cache.get(ck)
+        if ent is None:
+            rows, starts = [], [0]
+            for key, w, g in items:
+                master, m, v = self._shard_state(key, w)
+                ptrs = (w.data_ptr(), master.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr())
+                if any(x & 15 for x in ptrs) or w.dtype != items[0][1].dtype:
+                    raise ValueError("FusedAdamW.step_buckets: buckets must be 16-byte aligned and of one dtype")
+                rows.extend(ptrs + (w.numel(),))
+                starts.append(starts[-1] + (w.numel() + self._CHUNK - 1) // self._CHUNK)
+            n = len(items)
+            dev = items[0][1].device
+            devt = torch.tensor(rows + starts, dtype=torch.int64).to(dev)     # setup time, once
+            torch.cuda.current_stream(dev).synchronize()
+            ent = cache[ck] = (devt, n, starts[-1], items[0][1].dtype, dev)
+        devt, n, chunks, dtype, dev = ent
+        b1, b2 = self.betas
+        st = torch.cuda.current_stream(dev).cuda_stream
+        if dev_hyper:
+            _L.check(_L.load().mk_adamw_multi_dev(devt.data_ptr(), devt.data_ptr() + 6 * n * 8, n, chunks, b1, b2,
+                                                  self.eps, self.weight_decay, self._hyper_dev.data_ptr(),
+                                                  ops._DT[dtype], st), "mk_adamw_multi_dev")
+        else:
+            _L.check(_L.load().mk_adamw_multi(devt.data_ptr(), devt.data_ptr() + 6 * n * 8, n, chunks, self.lr,
+                                              b1, b2, self.eps, self.weight_decay, self.step_count, grad_scale,
+                                              ops._DT[dtype], st), "mk_adamw_multi")
+
     # ---- hipGraph form (train.GraphedStep) ------------------------------------------------------
+    _HYPER_SLOTS = 4
+
     def update_hyper(self, device, grad_scale: float = 1.0):
         """write {lr, 1 - beta1^step, 1 - beta2^step, grad_scale} of the CURRENT step_count to the
-        device buffer the captured optimizer launch reads (stream-ordered H2D from pinned memory)"""
+        device buffer the captured optimizer launch reads (stream-ordered H2D from pinned memory).
+        The copy reads the pinned slot when it EXECUTES, and graph launches are asynchronous (a
+        caller that never reads the loss runs many steps ahead of the GPU): each slot carries an
+        event recorded behind its copy and is not rewritten before that event has completed."""
         import ctypes as C
         from . import lib as _L
         if getattr(self, "_hyper_dev", None) is None:
             self._hyper_dev = torch.zeros(4, dtype=torch.float32, device=device)
-            self._hyper_host = [torch.zeros(4, dtype=torch.float32, pin_memory=True) for _ in range(4)]
+            self._hyper_host = [torch.zeros(4, dtype=torch.float32, pin_memory=True) for _ in range(self._HYPER_SLOTS)]
+            self._hyper_events = [None] * self._HYPER_SLOTS
             self._hyper_flip = 0
         bc = (C.c_float * 2)()
         _L.check(_L.load().mk_adamw_bias_correction(self.betas[0], self.betas[1], self.step_count, bc),
                  "mk_adamw_bias_correction")
-        self._hyper_flip = (self._hyper_flip + 1) % len(self._hyper_host)   # (copies of earlier steps in flight)
+        self._hyper_flip = (self._hyper_flip + 1) % self._HYPER_SLOTS
+        ev = self._hyper_events[self._hyper_flip]
+        if ev is not None:
+            ev.synchronize()          # the copy that last read this slot has executed
         h = self._hyper_host[self._hyper_flip]
         h[0], h[1], h[2], h[3] = float(self.lr), float(bc[0]), float(bc[1]), float(grad_scale)
         self._hyper_dev.copy_(h, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self._hyper_events[self._hyper_flip] = ev
 
     def prepare_graph(self, params):
         """allocations step_params_dev needs, made BEFORE the capture starts (pinned host memory

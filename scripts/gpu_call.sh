@@ -1,0 +1,30 @@
+#!/bin/bash
+# one gpurun call of round 3: everything is written under gpurun_out/r03/<tag>/
+# usage: scripts/gpu_call.sh <tag> <step> [<step> ...]   steps: probe tests bench flaky
+set -u
+tag=$1; shift
+out=gpurun_out/r03/$tag
+mkdir -p $out
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+for step in "$@"; do
+  t0=$(date +%s)
+  case $step in
+    probe)
+      timeout 300 python scripts/probe/gloo_cuda_race.py 150 0 > $out/gloo_probe_idle.txt 2>&1
+      timeout 400 python scripts/probe/gloo_cuda_race.py 150 1 > $out/gloo_probe_burner.txt 2>&1 ;;
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -q -rf --timeout 900 -p no:cacheprovider > $out/tests.log 2>&1
+      echo "pytest rc=$?" >> $out/tests.log ;;
+    tests_s)
+      timeout 1500 python -m pytest tests -m gpu -q -rf -s --timeout 900 -p no:cacheprovider > $out/tests.log 2>&1
+      echo "pytest rc=$?" >> $out/tests.log ;;
+    bench)
+      timeout 600 python bench.py --steps 8 --warmup 3 > $out/bench_cfg3.json 2> $out/bench_cfg3.err ;;
+    flaky)
+      timeout 900 python scripts/probe/flaky_dp.py 8 > $out/flaky.txt 2>&1 ;;
+    *) echo "unknown step $step" ;;
+  esac
+  echo "$step: $(( $(date +%s) - t0 )) s" >> $out/timing.txt
+done
+tail -5 $out/tests.log 2>/dev/null
+cat $out/timing.txt

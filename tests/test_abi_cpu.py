@@ -80,7 +80,7 @@ def test_product_ops_refuse_cpu_tensors():
 def test_product_path_never_imports_the_oracle():
     """the oracle is test infrastructure: importing the product package must not pull it in"""
     code = ("import sys; import macaw_llm_amd.modeling, macaw_llm_amd.engine, macaw_llm_amd.ops, "
-            "macaw_llm_amd.dp, macaw_llm_amd.optim, macaw_llm_amd.factory; "
+            "macaw_llm_amd.bucketed, macaw_llm_amd.train, macaw_llm_amd.optim, macaw_llm_amd.factory, macaw_llm_amd.preprocess; "
             "bad=[m for m in sys.modules if m=='oracle' or m.startswith('oracle.')]; print(bad); "
             "sys.exit(1 if bad else 0)")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)

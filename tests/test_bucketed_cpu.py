@@ -68,19 +68,23 @@ def _make_params():
     return big, odd, small, fa, fb, unused, lonely
 
 
-def _loss(ps, rank, micro=0):
+def _loss(ps, rank, micro=0, drop_small=False):
     big, odd, small, fa, fb, unused, lonely = ps
     scale = torch.arange(1280.).view(40, 32) / 1280
     m = micro + 1
-    return (FusedFn.apply(fa, fb, float(rank + 1) * m) + (big * scale * (rank + 1) * m).sum()
-            + (odd * (rank + 3)).sum() * m + (small * (2 * rank + 1)).sum() * m)
+    out = (FusedFn.apply(fa, fb, float(rank + 1) * m) + (big * scale * (rank + 1) * m).sum()
+           + (odd * (rank + 3)).sum() * m)
+    if not drop_small:        # drop_small: this rank's batch lacks the "modality" that feeds `small`
+        out = out + (small * (2 * rank + 1)).sum() * m
+    return out
 
 
-def _expected_grads(world, micros):
-    """rank-mean gradients summed over the micro-batches"""
+def _expected_grads(world, micros, small_ranks=None):
+    """rank-mean gradients summed over the micro-batches (small_ranks: the ranks whose batch feeds
+    `small`; the others contribute zeros to its mean)"""
     mr = sum(r + 1 for r in range(world)) / world
     mo = sum(r + 3 for r in range(world)) / world
-    ms = sum(2 * r + 1 for r in range(world)) / world
+    ms = sum(2 * r + 1 for r in (range(world) if small_ranks is None else small_ranks)) / world
     mm = sum(m + 1 for m in range(micros))
     scale = torch.arange(1280.).view(40, 32) / 1280
     fscale = torch.cat([torch.ones(16, 16), 2 * torch.ones(32, 16)]) * (torch.arange(768.).view(48, 16) / 768 + 1)
@@ -98,26 +102,31 @@ def _worker(rank, world, port, q, mode):
         ref = dict(big=big.detach().clone(), odd=odd.detach().clone(), small=small.detach().clone(),
                    fused=torch.cat([fa.detach(), fb.detach()]).clone(), unused=unused.detach().clone(),
                    lonely=lonely.detach().clone())
-        micros = 2 if mode == "accumulate" else 1
+        micros = 2 if mode in ("accumulate", "accumulate_mean") else 1
         clip = 3.0 if mode == "clip" else None
         opt = ShardSGD()
         rt = BucketedStep([big, odd, small, fb, fa, unused, lonely], opt, bucket_bytes=6000,
-                          accumulate_steps=micros, max_grad_norm=clip)
+                          accumulate_steps=micros, max_grad_norm=clip, zero1=(mode != "allreduce"),
+                          average_accumulated=(mode == "accumulate_mean"))
         ok = len(rt.buckets) >= 3
         # fused run kept gap-free and in address order inside its bucket
         ok = ok and fb.data.data_ptr() == fa.data.data_ptr() + fa.numel() * 4
         for b in rt.buckets:
             ok = ok and b.n % (8 * world) == 0
-        eg = _expected_grads(world, micros)
-        for it in range(2):
+        for it in range(3 if mode == "ragged" else 2):
+            # "ragged": from the second step on, the odd ranks' batches do not feed `small` -- its bucket
+            # completes during the backward on some ranks and only in finish() on the others; the
+            # collectives must still be issued in ONE order everywhere (rank-invariant schedule)
+            ragged = mode == "ragged" and it >= 1
+            eg = _expected_grads(world, micros, [r for r in range(world) if r % 2 == 0] if ragged else None)
             for m in range(micros):
                 rt.begin()
-                _loss(ps, rank, m).backward()
+                _loss(ps, rank, m, drop_small=ragged and rank % 2 == 1).backward()
                 rt.finish()
-            sc = 1.0
+            sc = 1.0 / micros if mode == "accumulate_mean" else 1.0
             if clip is not None:
                 nrm = math.sqrt(sum(float((g ** 2).sum()) for g in eg.values()))
-                sc = min(1.0, clip / (nrm + 1e-6))
+                sc = sc * min(1.0, clip / (nrm + 1e-6))
                 ok = ok and abs(float(rt.grad_norm) - nrm) <= 1e-4 * nrm
             for k in ("big", "odd", "small", "fused"):
                 ref[k] = ref[k] - 0.5 * sc * eg[k]
@@ -128,7 +137,8 @@ def _worker(rank, world, port, q, mode):
                     print("DEBUG", mode, world, rank, it, k, (got[k] - ref[k]).abs().max().item(), flush=True)
             # parameters without gradient: untouched (zero gradient in a used bucket; unused bucket skipped)
             ok = ok and torch.equal(unused.data, ref["unused"]) and torch.equal(lonely.data, ref["lonely"])
-        ok = ok and opt.step_count == 2
+        ok = ok and opt.step_count == (3 if mode == "ragged" else 2)
+        ok = ok and rt._order is not None and sorted(rt._order) == list(range(len(rt.buckets)))
         # replicas identical (the all-gather really distributed the other ranks' slices)
         flat = torch.cat([b.w for b in rt.buckets])
         others = [torch.empty_like(flat) for _ in range(world)]
@@ -139,10 +149,10 @@ def _worker(rank, world, port, q, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["plain", "accumulate", "clip"])
+@pytest.mark.parametrize("mode", ["plain", "accumulate", "accumulate_mean", "clip", "ragged", "allreduce"])
 @pytest.mark.parametrize("world", [2, 8])
 def test_bucketed_step_gloo(world, mode):
-    if world == 8 and mode != "plain" and (os.cpu_count() or 1) < 4:
+    if world == 8 and mode not in ("plain", "ragged") and (os.cpu_count() or 1) < 4:
         pytest.skip("too few cores for 8 ranks x 3 modes")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -22,7 +22,8 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from macaw_llm_amd.dp import GradSync, shard_batch
+        from legacy_steps import GradSync
+        from macaw_llm_amd.bucketed import shard_batch
         torch.manual_seed(0)                        # identical replicas
         big = torch.nn.Parameter(torch.randn(64, 48))
         small = torch.nn.Parameter(torch.randn(7))
@@ -67,7 +68,7 @@ def test_gradsync_gloo_world2():
 
 
 def test_shard_batch():
-    from macaw_llm_amd.dp import shard_batch
+    from macaw_llm_amd.bucketed import shard_batch
     assert [shard_batch(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]
     with pytest.raises(ValueError):
         shard_batch(10, 0, 4)
@@ -77,7 +78,7 @@ def _worker_overlapped(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from macaw_llm_amd.train import OverlappedStep
+        from legacy_steps import OverlappedStep
 
         class SGD:  # stands in for FusedAdamW (whose kernel needs the GPU)
             step_count = 0
@@ -123,7 +124,7 @@ def _worker_sharded(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from macaw_llm_amd.train import OverlappedStep
+        from legacy_steps import OverlappedStep
 
         class ShardSGD:  # FusedAdamW's interface (step_param / step_shard) with plain SGD arithmetic
             step_count = 0

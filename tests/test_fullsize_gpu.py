@@ -438,10 +438,98 @@ def test_full_llama7b_checkpointing_bit_identical_and_gradients_vs_oracle(dev):
         assert e_hip <= 1.5 * e_eag + 1e-2, (k, e_hip, e_eag)
 
 
+def _full_model_vs_oracle(dev, cfg, inp, keys, tag, seed=11):
+    """shared body of the full-depth parity tests: bf16 HIP engine vs the fp32 oracle run with plain
+    torch ops ON THE GPU (oracle.restate, pinned to the reference by tests/test_oracle.py), eager bf16
+    through the same oracle code as the yardstick.  Returns the measured errors; asserts the
+    integer outputs bit-exact, logits / loss / the gradients of `keys` no worse than 1.5 x eager bf16."""
+    from macaw_llm_amd.factory import build_model
+    model = build_model(cfg, dtype=torch.bfloat16, device=dev, seed=seed, fuse=True).eval()
+    model.zero_grad(set_to_none=True)
+    out = model(inputs=inp)
+    out.loss.backward()
+    with torch.no_grad():
+        emb, am, lab = model.prepare_inputs_for_generation(inp)
+    g_hip = {k: dict(model.named_parameters())[k].grad.detach().float().clone() for k in keys}
+    logits_hip, loss_hip = out.logits.detach().float().clone(), out.loss.item()
+    del out
+    model.zero_grad(set_to_none=True)
+    res = {}
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        sd = {k: v.to(dt) for k, v in _gpu_oracle_state(model).items()}
+        for k in keys:
+            sd[k] = sd[k].clone().requires_grad_(True)
+        fin = {k: (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}
+        r = restate.mm_forward(sd, fin, cfg)
+        r["loss"].backward()
+        res[name] = dict(logits=r["logits"].detach().float(), loss=r["loss"].item(),
+                         grads={k: sd[k].grad.float() for k in keys},
+                         am=r["attention_mask"], lab=r["labels"], emb=r["inputs_embeds"].detach().float())
+        del sd, r
+        torch.cuda.empty_cache()
+    ref = res["fp32"]
+    assert torch.equal(am, ref["am"]) and torch.equal(lab, ref["lab"])                 # INT: bit exact
+
+    def rel(a):
+        d = (a - ref["logits"]).abs()
+        return d.max().item() / ref["logits"].abs().max().item(), d.mean().item() / ref["logits"].abs().mean().item()
+
+    hip, eag = rel(logits_hip), rel(res["bf16"]["logits"])
+    emb_err = (emb.float() - ref["emb"]).abs().max().item() / ref["emb"].abs().max().item()
+    print(f"{tag} vs fp32 oracle (max/max, mean/mean): HIP bf16 {hip}, eager bf16 {eag}; inputs_embeds {emb_err:.3e}; "
+          f"loss HIP {loss_hip:.5f} eager {res['bf16']['loss']:.5f} fp32 {ref['loss']:.5f}")
+    assert hip[0] <= 1.5 * eag[0] + 5e-3 and hip[1] <= 1.5 * eag[1] + 2e-3, (hip, eag)
+    assert abs(loss_hip - ref["loss"]) <= 2e-2 * max(1.0, abs(ref["loss"]))
+    assert emb_err <= 5e-2
+    gerr = {}
+    for k in keys:
+        want = ref["grads"][k]
+        e_hip = (g_hip[k] - want).norm().item() / want.norm().item()
+        e_eag = (res["bf16"]["grads"][k] - want).norm().item() / want.norm().item()
+        gerr[k] = (e_hip, e_eag)
+        print(f"{tag} grad {k}: rel L2 err vs fp32 oracle: HIP bf16 {e_hip:.3e}, eager bf16 {e_eag:.3e}")
+        assert e_hip <= 1.5 * e_eag + 1e-2, (k, e_hip, e_eag)
+    del model, res
+    torch.cuda.empty_cache()
+    return hip, eag, gerr
+
+
+def test_cfg4_full_model_against_fp32_oracle_on_gpu(dev):
+    """BASELINE cfg 4 at FULL size against the ORACLE (round-2 verdict: "no oracle can run this" was
+    wrong -- at B = 1 the reference formulation's [1, 32, 2048, 2048] fp32 score tensors are 537 MB per
+    layer, trivial on a 288 GB part): 6 video frames through the second CLIP-L/14 + video self-attention,
+    30 s audio through Whisper-base, text to a total sequence of 2048, the 32-layer 7B backbone; logits,
+    loss and six gradients (top and bottom of the stack, alignment attention, embedding table) vs
+    fp32, eager bf16 as yardstick (modeling.py:397-522, 941-1048)."""
+    from macaw_llm_amd.factory import baseline_config, synthetic_inputs
+    cfg = baseline_config("real_7b")
+    L = 2048 - (2 * 2 + 6 + 51)
+    inp = synthetic_inputs(cfg, 1, L, modalities=("audios", "videos"), seed=9, device=dev)
+    keys = ["llm.lm_head.weight", "llm.model.norm.weight", "llm.model.layers.31.mlp.down_proj.weight",
+            "llm.model.layers.16.self_attn.q_proj.weight", "llm.model.layers.0.self_attn.v_proj.weight",
+            "video_align_attention.out_proj.weight"]
+    hip, eag, _ = _full_model_vs_oracle(dev, cfg, inp, keys, "cfg 4 (S = 2048, video + audio)", seed=3)
+    assert hip[1] < 0.15          # absolute sanity bound on the mean error (bf16 through 32 layers at S = 2048)
+
+
+def test_full_llama13b_against_fp32_oracle_on_gpu(dev):
+    """BASELINE cfg 5 backbone at FULL depth: the 40-layer LLaMA-13B (D = 5120, FF = 13824, 40 heads) +
+    CLIP-L/14 + Whisper-base, image + 30 s audio + 128 tokens, B = 2 (53 GB of fp32 oracle weights
+    beside the 27 GB bf16 model): logits, loss and six gradients vs the fp32 oracle, eager bf16 as
+    yardstick -- the same bar as the 7B test."""
+    from macaw_llm_amd.factory import baseline_config, synthetic_inputs
+    cfg = baseline_config("real_13b")
+    inp = synthetic_inputs(cfg, 2, 128, modalities=("images", "audios"), seed=5, device=dev)
+    keys = ["llm.lm_head.weight", "llm.model.norm.weight", "llm.model.layers.39.mlp.down_proj.weight",
+            "llm.model.layers.39.self_attn.q_proj.weight", "llm.model.layers.0.mlp.gate_proj.weight",
+            "llm.model.layers.0.self_attn.v_proj.weight"]
+    _full_model_vs_oracle(dev, cfg, inp, keys, "13B (cfg 5 backbone)")
+
+
 def test_cfg4_sequence_2048_video_audio_text_full_model(dev):
-    """BASELINE cfg 4 at full size: 6 video frames + 30 s audio + text, total sequence 2048, the
-    32-layer 7B backbone.  No oracle can run this; checked: prefix geometry (integer, exact),
-    finite loss / logits / gradients, padded tail rows do not influence valid logits, and the
+    """BASELINE cfg 4 at full size, B = 2 with right padding (the oracle comparison is
+    test_cfg4_full_model_against_fp32_oracle_on_gpu above): prefix geometry (integer, exact), finite
+    loss / logits / gradients, padded tail rows do not influence valid logits, and the
     activation-checkpointed step reproduces the plain one bit for bit at this length."""
     from macaw_llm_amd.factory import baseline_config, build_model, synthetic_inputs
     cfg = baseline_config("real_7b")
@@ -488,9 +576,13 @@ def test_decode_step_real_dimension_layer_graphable_vs_separate_kernels(dev, B):
     """One LLaMA-7B-dimension decode step of a layer: the graph-capturable path (position read from
     device memory; RMSNorm / SwiGLU folded into the weight-streaming linears where they fit, RoPE +
     cache append + attention in one launch) against the eager path built from the separate kernels
-    (rmsnorm, linear, mk_rope, copy, fused attention with Lq = 1, swiglu).  The appended cache row
-    (rotated key | value) must be bit-identical; the layer output agrees to bf16 rounding of the
-    different summation orders."""
+    (rmsnorm, linear, mk_rope, copy, fused attention with Lq = 1, swiglu).
+      * GIVEN THE SAME q|k|v rows, the fused RoPE + append writes a cache row (rotated key | value)
+        that is BIT-IDENTICAL to mk_rope + copy (asserted with torch.equal below);
+      * end to end the two paths compute q|k|v with different kernels (RMSNorm folded into the weight
+        stream vs rmsnorm + GEMM: other summation order, an rstd ulp), so the appended row agrees in
+        > 98 % of its elements exactly and everywhere to bf16 rounding, and the layer output to
+        2^-6 of its largest magnitude."""
     g = torch.Generator().manual_seed(11 + B)
     T0, Tmax, hd = 150, 160, D // H
     wqkv = _bf(torch.randn(3 * D, D, generator=g) * 0.02).to(dev)
@@ -514,8 +606,22 @@ def test_decode_step_real_dimension_layer_graphable_vs_separate_kernels(dev, B):
         out_g = eng.llama_layer_cached(x2, B, 1, 0, kv_g, Tmax, pos, cos, sin, *args, t_dev=t_dev)
     assert torch.equal(kv_e[:, :T0], kv_g[:, :T0]) and torch.equal(kv_e[:, T0 + 1:], kv_g[:, T0 + 1:])
     same = (kv_e[:, T0] == kv_g[:, T0]).float().mean().item()
-    # (with the fused RMSNorm the q|k|v projection may differ by an rstd ulp in a few elements)
     assert same > 0.98, same
+    rd = (kv_e[:, T0].float() - kv_g[:, T0].float()).abs().max().item()
+    assert rd <= 2.0 ** -7 * kv_e[:, T0].float().abs().max().item() + 1e-3, rd
+    # same q|k|v rows in, fused RoPE + append vs mk_rope + copy: bit-identical cache row
+    with torch.no_grad():
+        _, y1, _ = ops.rmsnorm_fwd(x2, ln1, 1e-6)
+        qkv = ops.linear_fwd(y1, wqkv)
+        kv_a, kv_b = cache0.clone().to(dev), cache0.clone().to(dev)
+        att = torch.empty((B, D), dtype=torch.bfloat16, device=dev)
+        ops.decode_step_attn(qkv.clone(), qkv, qkv, 3 * D, cos, sin, kv_a, t_dev, Tmax, B, H, hd, att,
+                             1.0 / math.sqrt(hd), k_off=D, v_off=2 * D)
+        q2 = qkv.clone()
+        ops.rope_(q2[:, :2 * D], cos, sin, pos, 2 * H, hd)
+        ops.copy2d(q2, kv_b, 1, 2 * D, 3 * D, 2 * D, batch=B, s_src=3 * D, s_dst=Tmax * 2 * D, src_off=D,
+                   dst_off=T0 * 2 * D)
+    assert torch.equal(kv_a, kv_b)
     d = (out_e.float() - out_g.float()).abs().max().item()
     ref = out_e.float().abs().max().item()
     assert d <= 2.0 ** -6 * ref + 1e-3, (d, ref)

@@ -1,8 +1,9 @@
-"""GPU: the training-step runtime (train.OverlappedStep + optim.FusedAdamW) through RCCL.
-The box has one GPU, so the process group has ONE rank: the collectives are trivial but the
+"""GPU: the training-step runtime (bucketed.BucketedStep + optim.FusedAdamW) through RCCL, against
+the per-tensor reference steps of rounds 1-2 (tests/legacy_steps.py).
+The box has one GPU, so an RCCL process group has ONE rank: the collectives are trivial but the
 whole call path of the multi-GPU step (async reduce-scatter on RCCL's stream -> shard AdamW on
-the side stream -> in-place all-gather, small-tensor coalescing, stream joins) executes for real
-and must reproduce the collective-free step bit for bit."""
+the side stream -> in-place all-gather, stream joins) executes for real and must reproduce the
+collective-free step bit for bit; world size 2 runs as two processes sharing the GPU over gloo."""
 import socket
 
 import pytest
@@ -26,7 +27,7 @@ def _free_port():
 
 def _run(dev, fx, cfg, steps, **kw):
     from macaw_llm_amd.optim import FusedAdamW
-    from macaw_llm_amd.train import OverlappedStep
+    from legacy_steps import OverlappedStep
     model = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=True).eval()   # eval: no dropout RNG
     params = [p for p in model.parameters() if p.requires_grad]
     opt = FusedAdamW(params, lr=1e-3, weight_decay=0.01)
@@ -79,7 +80,7 @@ def _worker_two_ranks_one_gpu(rank, world, port, q, shard):
         from oracle import configs
         from test_model_gpu import build_model, to_dev
         from macaw_llm_amd.optim import FusedAdamW
-        from macaw_llm_amd.train import OverlappedStep
+        from legacy_steps import OverlappedStep
         dev = torch.device("cuda:0")
         fx = load_case("micro_all")
         cfg = configs.get(fx["config_name"])
@@ -192,31 +193,87 @@ def test_bucketed_step_is_bit_identical_to_the_per_tensor_step(dev):
         dist.destroy_process_group()
 
 
-def test_bucketed_accumulation_and_clipping(dev):
-    """two identical micro-batches accumulate to 2 x the gradient; with max_grad_norm the update
-    uses grad_scale = max_norm / ||g||: compare against the per-tensor step fed the same scale."""
+@pytest.mark.parametrize("average", [True, False])
+def test_bucketed_accumulation_and_clipping(dev, average):
+    """two identical micro-batches: average_accumulated (the default; HF Trainer / DeepSpeed divide the
+    loss by gradient_accumulation_steps, train.sh:29) gives the gradient of ONE batch, the sum form 2 x
+    it; with max_grad_norm the update uses grad_scale = max_norm / ||g||: compare against the
+    per-tensor step fed the same gradient and scale."""
     from macaw_llm_amd.optim import FusedAdamW
-    from macaw_llm_amd.train import OverlappedStep
     fx = load_case("micro_all")
     cfg = configs.get(fx["config_name"])
-    # reference: one step, gradients doubled by hand, clipped by hand
+    mult = 1.0 if average else 2.0
     model = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=True).eval()
     params = [p for p in model.parameters() if p.requires_grad]
     inp = to_dev(fx["inputs"], dev)
     model(inputs=inp).loss.backward()
     for p in params:
         if p.grad is not None:
-            p.grad = (p.grad.float() * 2).to(p.grad.dtype)
+            p.grad = (p.grad.float() * mult).to(p.grad.dtype)
     gn = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in params if p.grad is not None)).item()
     max_norm = 0.5 * gn
     opt = FusedAdamW(params, lr=1e-3, weight_decay=0.01)
     opt.step(grad_scale=min(1.0, max_norm / (gn + 1e-6)))
     want = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad and n in fx["state"]}
-    _, got, rt = _run_bucketed(dev, fx, cfg, 1, micros=2, max_grad_norm=max_norm)
+    _, got, rt = _run_bucketed(dev, fx, cfg, 1, micros=2, max_grad_norm=max_norm, average_accumulated=average)
     assert abs(float(rt.grad_norm) - gn) <= 2e-3 * gn
     for n in got:
         # (bf16 accumulation g + g is exact; the clip factor differs in the last fp32 digits)
         assert (got[n].float() - want[n].float()).abs().max().item() <= 2e-3 * max(1e-3, want[n].float().abs().max().item()), n
+
+
+def test_bucketed_step_built_on_an_unfused_model_still_trains_every_projection(dev):
+    """round-2 advisor finding (high): BucketedStep built BEFORE the first forward of a model whose
+    q|k|v / gate|up were not fused yet, followed by the lazy fusion of modeling.AUTO_FUSE, re-homed the
+    parameters OUT of the buckets -- the optimizer kept updating the bucket, the model computed with
+    the stale copies, silently.  Now (a) model= fuses first, (b) without it the pinned parameters are
+    never moved (per-projection GEMMs), (c) begin() verifies the homes.  Both ways must train q|k|v
+    and agree with the fused-first run to bf16 rounding of the different GEMM shapes."""
+    from macaw_llm_amd.optim import FusedAdamW
+    from macaw_llm_amd.bucketed import BucketedStep
+    from macaw_llm_amd import modeling as M
+    fx = load_case("micro_all")
+    cfg = configs.get(fx["config_name"])
+    inp = to_dev(fx["inputs"], dev)
+
+    def run(mode):
+        model = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=(mode == "fused")).eval()
+        l0 = model.llm.model.layers[0]
+        if mode != "fused":
+            assert M._rows_view([l0.self_attn.q_proj.weight, l0.self_attn.k_proj.weight,
+                                 l0.self_attn.v_proj.weight]) is None            # really unfused at build
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = FusedAdamW(params, lr=1e-3, weight_decay=0.0)
+        rt = BucketedStep(params, opt, bucket_bytes=64 << 10, model=model if mode == "model_arg" else None)
+        w0 = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad and n in fx["state"]}
+        losses = []
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for _ in range(3):
+                rt.begin()
+                loss = model(inputs=inp).loss
+                loss.backward()
+                rt.finish()
+                losses.append(loss.item())
+        torch.cuda.synchronize()
+        rt._check_homes()                     # parameters still view their bucket slots after three forwards
+        fused_now = all(v is not None for v in l0.fused_weights())
+        rt.remove()
+        w1 = {n: p.detach().clone() for n, p in model.named_parameters() if n in w0}
+        return losses, w0, w1, fused_now
+
+    ref = run("fused")
+    for mode in ("model_arg", "pinned_unfused"):
+        losses, w0, w1, fused_now = run(mode)
+        assert fused_now == (mode == "model_arg")
+        assert losses[2] < losses[0]
+        for n in w1:
+            if any(k in n for k in ("q_proj", "k_proj", "v_proj", "gate_proj", "up_proj")) and "llm." in n:
+                assert not torch.equal(w0[n], w1[n]), f"{mode}: {n} was not trained"
+            d = (w1[n].float() - ref[2][n].float()).abs().max().item()
+            assert d <= 4e-3 + 2e-2 * ref[2][n].float().abs().max().item(), (mode, n, d)
+        assert abs(losses[2] - ref[0][2]) <= 2e-2 * abs(ref[0][2])
 
 
 def _worker_bucketed_two_ranks(rank, world, port, q):
@@ -284,27 +341,11 @@ def test_bucketed_two_ranks_share_one_gpu_through_gloo(dev):
         assert a[n] == b[n], n
     other = globals().get("_TWO_RANK_RESULTS", {}).get(True)
     if other is not None:
+        # same rank-mean gradients, same kernel body: bit-identical to the per-tensor ZeRO-1 step.  (Round 2
+        # retried here on a rare one-weight mismatch; the cause was found and fixed in round 3 -- DESIGN.md
+        # section 6 "the world-2 mismatch" -- and the comparison is strict again.)
         bad = [n for n in a if a[n] != other[n]]
-        if bad:
-            # seen twice in ~40 runs (one weight, replicas still identical; 28 stand-alone repetitions of
-            # both steps, scripts/probe/flaky_dp.py, were bit-identical): repeat both steps once and fail
-            # only if the disagreement is reproducible
-            import warnings
-            warnings.warn(f"bucketed vs per-tensor ZeRO-1 step differed in {bad[:4]}: repeating both")
-            again = {}
-            for key, tgt, extra in (("t", _worker_two_ranks_one_gpu, (True,)), ("b", _worker_bucketed_two_ranks, ())):
-                q2 = ctx.Queue()
-                port2 = _free_port()
-                ps = [ctx.Process(target=tgt, args=(r, 2, port2, q2) + extra) for r in range(2)]
-                for p_ in ps:
-                    p_.start()
-                r2 = sorted((q2.get(timeout=300) for _ in ps), key=lambda t: t[0])
-                for p_ in ps:
-                    p_.join(timeout=60)
-                assert r2[0][1] != "error", r2[0][2]
-                again[key] = r2[0][2]
-            for n in a:
-                assert again["b"][n] == again["t"][n], n
+        assert not bad, bad[:8]
 
 
 def test_graphed_step_is_bit_identical_to_the_eager_step(dev):
@@ -314,6 +355,7 @@ def test_graphed_step_is_bit_identical_to_the_eager_step(dev):
     mode), a changing learning rate, and an eager step interleaved after the capture."""
     from macaw_llm_amd.optim import FusedAdamW
     from macaw_llm_amd.train import GraphedStep
+    from macaw_llm_amd.bucketed import BucketedStep
     fx = load_case("micro_all")
     cfg = configs.get(fx["config_name"])
     inp = to_dev(fx["inputs"], dev)
@@ -322,7 +364,7 @@ def test_graphed_step_is_bit_identical_to_the_eager_step(dev):
         model = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=True).train()
         params = [p for p in model.parameters() if p.requires_grad]
         opt = FusedAdamW(params, lr=1e-3, weight_decay=0.01)
-        gs = GraphedStep(model, lambda: model(inputs=inp).loss, params, opt)
+        gs = GraphedStep(model, lambda: model(inputs=inp).loss, BucketedStep(params, opt, bucket_bytes=64 << 10))
         losses = []
         for it in range(6):
             opt.lr = 1e-3 * (1.0 - 0.1 * it)
@@ -330,8 +372,11 @@ def test_graphed_step_is_bit_identical_to_the_eager_step(dev):
                 losses.append(float(gs.step()))
             else:
                 losses.append(float(gs.eager_step()))
+        torch.cuda.synchronize()
+        gs.rt.remove()
         # (parameters outside the fixture's state dict are random per build: compare the trained ones)
-        return losses, {n: p.detach().clone() for n, p in model.named_parameters() if p.grad is not None}, gs
+        return losses, {n: p.detach().clone() for n, p in model.named_parameters()
+                        if p.requires_grad and n in fx["state"]}, gs
 
     le, pe, _ = run(False)
     lg, pg, gs = run(True)
@@ -341,3 +386,37 @@ def test_graphed_step_is_bit_identical_to_the_eager_step(dev):
     assert pe.keys() == pg.keys() and len(pe) > 20
     for n in pe:
         assert torch.equal(pe[n], pg[n]), n
+
+
+@pytest.mark.parametrize("inject", [None, "1"])
+def test_bench_py_runs_its_n_gt_1_branch_with_two_ranks_on_this_gpu(dev, inject):
+    """bench.py's N > 1 branch (process-group setup, BucketedStep ZeRO-1 with the frozen bucket order,
+    cross-rank agreement on a failed setup step, max-over-ranks timing, describe()) had never executed
+    before the driver's 8-GPU run (round-2 verdict).  Here it runs as two torchrun ranks sharing this
+    GPU over gloo (MACAW_SHARE_GPU / MACAW_DIST_BACKEND; 2-layer model, marked invalid as a
+    benchmark).  inject="1": rank 1 fails its setup step -- BOTH ranks must fall back together to
+    all-reduce + replicated AdamW and say so in config.parallelism."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MACAW_SHARE_GPU="1", MACAW_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if inject is not None:
+        env["MACAW_BENCH_INJECT_FAIL"] = inject
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--layers", "2", "--batch-per-gpu", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]           # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["value"] > 0
+    assert "invalid" in d
+    par = d["config"]["parallelism"]
+    if inject is None:
+        assert "ZeRO-1" in par and "DEGRADED" not in par, par
+    else:
+        assert "DEGRADED" in par and "all-reduce / replicated AdamW" in par, par
+    assert d["roofline"]["launches_per_step"] > 0 and d["config"]["loss"] == d["config"]["loss"]   # not NaN
