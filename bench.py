@@ -60,7 +60,7 @@ CONFIGS = {
     5: dict(model="real_13b", modalities=("images", "audios"), batch=32, text_len=128, seq=144, alg_tf=12.07,
             fp8=True, ckpt=True,
             workload="BASELINE cfg 5: LLaMA-13B backbone (D=5120, 40 layers), image + 30 s audio + 128-token text "
-                     "(S=144), fp8 (e4m3) MFMA forward of the q|k|v and alignment K/V GEMMs, activation "
+                     "(S=144), fp8 (e4m3) MFMA forward + grad-input of the q|k|v and alignment K/V GEMMs, activation "
                      "checkpointing on, whole training state on one GPU"),
 }
 
@@ -244,6 +244,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="force the cfg 5 precision (q|k|v and alignment K/V "
                     "forward GEMMs on the fp8 MFMA path) on another configuration")
+    ap.add_argument("--no-fp8", action="store_true", help="cfg 5 in pure bf16 (the yardstick of its fp8 speed-up)")
+    ap.add_argument("--fp8-mlp", action="store_true", help="extend the fp8 path to the gate|up / down GEMMs (beyond "
+                    "BASELINE cfg 5's wording; reported separately)")
     ap.add_argument("--checkpoint", action="store_true", help="force activation checkpointing of the decoder layers")
     ap.add_argument("--layers", type=int, default=None, help="debug only: truncates the LLaMA stack "
                     "(the printed line is then marked invalid)")
@@ -283,14 +286,14 @@ def main():
         spec["model"] = args.model
     if args.batch_per_gpu:
         spec["batch"] = args.batch_per_gpu
-    spec["fp8"] = spec["fp8"] or args.fp8
+    spec["fp8"] = (spec["fp8"] or args.fp8 or args.fp8_mlp) and not args.no_fp8
     spec["ckpt"] = spec["ckpt"] or args.checkpoint
     cfg = baseline_config(spec["model"])
     if args.layers is not None:
         cfg["llama"]["num_hidden_layers"] = args.layers
     model = build_model(cfg, dtype=torch.bfloat16, device=dev, seed=1234).train()
     if spec["fp8"]:
-        model.set_fp8(qkv=True, align=True)
+        model.set_fp8(qkv=True, align=True, mlp=args.fp8_mlp)
     if spec["ckpt"]:
         model.llm.model.gradient_checkpointing = True     # modeling.py:474-489
     params = [p for p in model.parameters() if p.requires_grad]
@@ -339,16 +342,19 @@ def main():
     # one untimed SETUP step: materialises the optimizer state (fp32 master / m / v, 84 GB at 7B),
     # the allocator pools and the frozen bucket order, like building the model.  The W warm-up steps
     # follow.  N > 1: the ZeRO-1 collectives are the one path a 1-GPU pool cannot run on real RCCL.
-    # If the setup step raises on ANY rank, ALL ranks agree on it (the verdict travels through a
-    # gloo side group, which does not depend on the state of the RCCL communicator) and continue
-    # together on all-reduce + replicated AdamW (zero1=False), and the line SAYS SO in
-    # `config.parallelism`: a degraded run must not pass as ZeRO-1; a failure at N = 1 is an error.
+    # If the setup step raises (the realistic N > 1 failures are symmetric: an unsupported collective,
+    # an out-of-memory at the same point, a bug on the path -- every rank raises in the same place),
+    # ALL ranks agree on it (the verdict travels through a gloo side group, which does not depend on
+    # the state of the RCCL communicator) and continue together on all-reduce + replicated AdamW
+    # (zero1=False), and the line SAYS SO in `config.parallelism`: a degraded run must not pass as
+    # ZeRO-1; a failure at N = 1 is an error.  (A rank that dies ALONE leaves the others inside a
+    # collective; that ends at the process group's watchdog timeout, as in any RCCL job.)
     degraded = None
     side_group = dist.new_group(backend="gloo") if (world > 1 and dist.get_backend() != "gloo") else None
     err = None
-    inject = os.environ.get("MACAW_BENCH_INJECT_FAIL")     # test hook: "<rank>" fails that rank's setup step
+    inject = os.environ.get("MACAW_BENCH_INJECT_FAIL")     # test hook: "all" fails every rank's ZeRO-1 setup step
     try:
-        if inject is not None and int(inject) == rank:
+        if inject is not None and (inject == "all" or inject == str(rank)):
             raise RuntimeError("injected setup-step failure (MACAW_BENCH_INJECT_FAIL)")
         step()
         torch.cuda.synchronize()
@@ -407,7 +413,10 @@ def main():
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if not spec["fp8"] else "bf16 + fp8(e4m3) forward of q|k|v and alignment K/V GEMMs",
+            "dtype": "bf16" if not spec["fp8"] else
+                     ("bf16 + fp8 (e4m3, per-row / per-channel scales) forward and grad-input GEMMs of q|k|v and the "
+                      "alignment K/V projection" + (" and of gate|up / down" if args.fp8_mlp else "")
+                      + "; grad-weight GEMMs, attention and everything else bf16"),
             "data": "synthetic",
             "config": {"workload": (spec["workload"] + "; fwd+bwd+fused AdamW, encoders frozen as "
                                     "run_clm_llms.py:390-393, alignment-attention dropout on"),

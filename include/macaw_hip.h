@@ -34,7 +34,7 @@ extern "C" {
 #define MK_FP8 3 /* OCP e4m3fn bytes: mk_gemm operands / mk_fp8_quantize output only */
 
 /* library identification: returns MK_ABI_VERSION */
-#define MK_ABI_VERSION 5
+#define MK_ABI_VERSION 6
 int mk_abi_version(void);
 
 /* ------------------------------------------------------------------ GEMM --
@@ -85,6 +85,10 @@ typedef struct mk_gemm_desc {
                            is not a multiple of 64 can still take the MFMA tile kernels (the other
                            operand must be reduction-major or padded the same way) */
 } mk_gemm_desc;
+#define MK_GEMM_SCALE_VEC 4   /* scale_a / scale_b are VECTORS: scale_a[M] per row of A (= output row),
+                                 scale_b[N] per row of B (= output column): C = alpha-free
+                                 act(acc * scale_a[m] * scale_b[n] + bias) ... (per-row / per-channel
+                                 fp8 de-quantisation, mk_fp8_quantize_rows / _cols_t) */
 #define MK_GEMM_A_KPAD_ZERO 1
 #define MK_GEMM_B_KPAD_ZERO 2
 int mk_gemm(const mk_gemm_desc* d, void* stream);
@@ -338,6 +342,17 @@ int mk_set_dropout_seed_offset(const uint64_t* dev_ptr);
  * amax_ws: device float[1] scratch.  n % 8 == 0, 16-byte aligned x, 8-byte aligned q. */
 int mk_fp8_quantize(const void* x, int64_t n, int32_t dtype, uint8_t* q, float* amax_ws,
                     float* dequant_scale, void* stream);
+/* Per-ROW scaled e4m3 of a row-major (pitched) [rows, cols] bf16 matrix (activations, gradients,
+ * K-major weights = one scale per output channel): q[r, c] = e4m3(x[r, c] * 448 / amax_r),
+ * scales[r] = amax_r / 448 (1 for a zero row).  cols % 8 == 0; GEMM operands need cols % 128 == 0. */
+int mk_fp8_quantize_rows(const void* x, int32_t rows, int32_t cols, int64_t ld, int32_t dtype,
+                         uint8_t* q, int64_t ldq, float* scales, void* stream);
+/* Per-COLUMN scaled e4m3 with TRANSPOSED output: qt[c, r] = e4m3(x[r, c] * 448 / amax_c),
+ * scales[c] = amax_c / 448 -- the operand of the fp8 grad-input GEMM dx = dy W (the reduction runs
+ * over the rows of W [out, in], modeling.py:159-162: nn.Linear stores [out, in]), i.e. W^T K-major
+ * with one scale per input channel.  amax_ws: device float[cols] scratch.  rows, cols % 8 == 0. */
+int mk_fp8_quantize_cols_t(const void* x, int32_t rows, int32_t cols, int64_t ld, int32_t dtype,
+                           uint8_t* qt, int64_t ldqt, float* scales, float* amax_ws, void* stream);
 
 /* ------------------------------------------------------ host-input pipeline --
  * The per-step CPU work of llm_trainer.py:306-381 (get_self_inputs) moved to the GPU.

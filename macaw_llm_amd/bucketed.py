@@ -436,6 +436,7 @@ class BucketedStep:
         for h in self._gathers:                 # the next forward reads the gathered parameters
             h.wait()
         self._gathers.clear()
+        ops.bump_weight_version()               # cached fp8 copies of the weights are stale now
 
     def _clip_scale(self, acc_scale: float):
         """grad_scale = acc_scale * min(1, max_norm / (||g|| + 1e-6)) as torch.nn.utils.clip_grad_norm_;

@@ -86,7 +86,18 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs a) {
   for (int d = 0; d < NDB; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+  // Online softmax state in the exp2 domain: m_run = running max of t = s * scale * log2(e), l_run =
+  // sum of 2^(t - m_run).  (v_exp_f32 IS exp2: folding scale and log2(e) into one FMA with the max
+  // removes a multiply per score; the natural-log lse is recovered at the end.)
   float m_run = -INFINITY, l_run = 0.f;
+  const float c2 = a.scale * 1.4426950408889634f;
+  // Lazy rescaling (cdna_hip_programming.md T13): the accumulators are rescaled only when some row's
+  // maximum grew by more than 2^DEFER since the last rescale; otherwise the old maximum is kept and
+  // p = 2^(t - m_old) <= 2^DEFER.  Every quantity still at the old maximum (O, l) is rescaled in the
+  // same place, before this sub-block's P exists, and all earlier P V products are complete (the
+  // code is sequential per wave): the "textbook order", no pending-tile hazard.  DEFER = 0 rescales
+  // on every growth (the round-2 behaviour).
+  constexpr float DEFER = 6.0f;          // 2^6 = 64: p, l stay far inside fp32 / bf16 range
 
   // keys this block has to visit (causal: up to the last query row of the block)
   const int shift = a.Lk - a.Lq;         // query i may see keys <= i + shift
@@ -125,6 +136,10 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs a) {
     }
     __syncthreads();
     if (q0 >= a.Lq) continue;            // wave has no rows (still takes part in the barriers)
+    // Interior tile: every key of the tile is valid and visible to every query row of this wave --
+    // no mask arithmetic at all (at S = 2048 all but the last two tiles of a block).  Wave-uniform.
+    bool interior = (__builtin_amdgcn_ballot_w64(ldsM[l] != 0) == ~0ull);
+    if (CAUSAL) interior = interior && (kbase + KT - 1 <= q0 + shift);
 
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
@@ -139,36 +154,50 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs a) {
       }
       // ---- mask + online softmax (this lane: query qg, keys key(r)) ----
       float mx = -INFINITY;
-      int mk[16];
+      if (interior) {
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int4 m4 = *reinterpret_cast<const int4*>(ldsM + sb * 32 + 8 * g4 + 4 * half);
-        mk[4 * g4] = m4.x; mk[4 * g4 + 1] = m4.y; mk[4 * g4 + 2] = m4.z; mk[4 * g4 + 3] = m4.w;
-      }
+        for (int r = 0; r < 16; ++r) { s[r] *= c2; mx = fmaxf(mx, s[r]); }
+      } else {
+        int mk[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kg = kbase + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        bool ok = mk[r] != 0;
-        if (CAUSAL) ok = ok && (kg <= qg + shift);
-        s[r] = ok ? s[r] * a.scale : -INFINITY;
-        mx = fmaxf(mx, s[r]);
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int4 m4 = *reinterpret_cast<const int4*>(ldsM + sb * 32 + 8 * g4 + 4 * half);
+          mk[4 * g4] = m4.x; mk[4 * g4 + 1] = m4.y; mk[4 * g4 + 2] = m4.z; mk[4 * g4 + 3] = m4.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kg = kbase + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          bool ok = mk[r] != 0;
+          if (CAUSAL) ok = ok && (kg <= qg + shift);
+          s[r] = ok ? s[r] * c2 : -INFINITY;
+          mx = fmaxf(mx, s[r]);
+        }
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
-      float ps = 0.f;
+      // rescale only if some row of the wave needs it (NaN-safe: -inf - -inf compares false -> rescale)
+      if (!__all((mx - m_run <= DEFER) ? 1 : 0)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+        m_run = m_new;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[r] = (s[r] == -INFINITY) ? 0.f : __expf(s[r] - m_new);
-        ps += s[r];
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+      }
+      float ps = 0.f;
+      if (interior) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_run); ps += s[r]; }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[r] = (s[r] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(s[r] - m_run);
+          ps += s[r];
+        }
       }
       ps += __shfl_xor(ps, 32, 64);
-      l_run = l_run * alpha + ps;
-      m_run = m_new;
-#pragma unroll
-      for (int d = 0; d < NDB; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+      l_run += ps;
       bf16x8 pf[2];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { pf[0][e] = (bf16)s[e]; pf[1][e] = (bf16)s[8 + e]; }
@@ -205,8 +234,9 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs a) {
       for (int e = 0; e < 4; ++e) ov[e] = (bf16)(oacc[d][4 * q4 + e] * inv);
       *reinterpret_cast<bf16x4*>(O + d * 32 + 8 * q4 + 4 * half) = ov;
     }
-  if (a.lse && half == 0)
-    a.lse[((long)b * a.H + h) * a.Lq + qg] = (l_run > 0.f) ? m_run + __logf(l_run) : -INFINITY;
+  if (a.lse && half == 0)   // natural-log lse = (m2 + log2(l)) * ln(2)
+    a.lse[((long)b * a.H + h) * a.Lq + qg] =
+        (l_run > 0.f) ? (m_run + __log2f(l_run)) * 0.6931471805599453f : -INFINITY;
 }
 
 }  // namespace

@@ -410,6 +410,99 @@ __global__ __launch_bounds__(256) void fp8_quant_kernel(const T* x, long n, uint
   }
 }
 
+
+// ---- per-ROW scaled e4m3 (activations, gradients, K-major weights): one workgroup per row.
+// q[r, c] = e4m3(clamp(x[r, c] * 448 / amax_r)), scale[r] = amax_r / 448 (1 for an all-zero row).
+// The row is read twice (the second pass hits L2): HBM traffic = 2 B in + 1 B out per element.
+MK_DEV int2 fp8_pack8(const float (&v)[8], float sc) {
+  float t[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) t[k] = fminf(fmaxf(v[k] * sc, -448.f), 448.f);
+  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], 0, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], hi, true);
+  return make_int2(lo, hi);
+}
+
+__global__ __launch_bounds__(256) void fp8_rowquant_kernel(const bf16* x, long ld, int cols, uint8_t* q,
+                                                           long ldq, float* scale) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const bf16* xr = x + row * ld;
+  const int nch = cols / 8;
+  float m = 0.f;
+  for (int c = threadIdx.x; c < nch; c += 256) {
+    float v[8];
+    VecIO<bf16>::load(xr + c * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(v[k]));
+  }
+  m = block_max<256>(m, red);
+  const float sc = m > 0.f ? 448.f / m : 1.f;
+  if (threadIdx.x == 0) scale[row] = m > 0.f ? m / 448.f : 1.f;
+  uint8_t* qr = q + row * ldq;
+  for (int c = threadIdx.x; c < nch; c += 256) {
+    float v[8];
+    VecIO<bf16>::load(xr + c * 8, v);
+    *reinterpret_cast<int2*>(qr + c * 8) = fp8_pack8(v, sc);
+  }
+}
+
+// ---- per-COLUMN scaled e4m3, TRANSPOSED output (the weight of a grad-input GEMM: dx = dy W reduces
+// over W's ROWS, so the fp8 MFMA wants W^T K-major with one scale per row of W^T = per column of W).
+// pass 1: amax[c] = max_r |x[r, c]| (row slabs, atomicMax on the bit pattern of a non-negative float)
+__global__ __launch_bounds__(256) void fp8_colamax_kernel(const bf16* x, long ld, int rows, int cols,
+                                                          float* amax, int rows_per_block) {
+  const int c8 = blockIdx.x * 256 + threadIdx.x;          // this thread's group of 8 columns
+  if (c8 * 8 >= cols) return;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < r1; ++r) {
+    float v[8];
+    VecIO<bf16>::load(x + (long)r * ld + c8 * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], fabsf(v[k]));
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    atomicMax(reinterpret_cast<unsigned int*>(amax) + c8 * 8 + k, __float_as_uint(m[k]));
+}
+// pass 2: qt[c, r] = e4m3(x[r, c] * 448 / amax[c]) for a 64 x 64 tile through LDS; scale[c] = amax[c] / 448
+__global__ __launch_bounds__(256) void fp8_quant_t_kernel(const bf16* x, long ld, int rows, int cols,
+                                                          const float* amax, uint8_t* qt, long ldqt,
+                                                          float* scale) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+  // load: thread t covers row (t >> 3) + 32 * i, columns 8 * (t & 7) .. + 8
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (t >> 3) + 32 * i, c = 8 * (t & 7);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r0 + r < rows && c0 + c < cols) VecIO<bf16>::load(x + (long)(r0 + r) * ld + c0 + c, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tile[r][c + k] = v[k];
+  }
+  __syncthreads();
+  // store: thread t covers output row (column of x) (t >> 3) + 32 * i, 8 consecutive r
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (t >> 3) + 32 * i, r = 8 * (t & 7);
+    if (c0 + c >= cols || r0 + r >= rows) continue;
+    const float am = amax[c0 + c];
+    const float sc = am > 0.f ? 448.f / am : 1.f;
+    if (blockIdx.y == 0 && r == 0) scale[c0 + c] = am > 0.f ? am / 448.f : 1.f;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = tile[r + k][c];
+    *reinterpret_cast<int2*>(qt + (long)(c0 + c) * ldqt + r0 + r) = fp8_pack8(v, sc);
+  }
+}
+__global__ __launch_bounds__(256) void fp8_zero_n_kernel(float* p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
 }  // namespace
 
 #define MK_ST reinterpret_cast<hipStream_t>(stream)
@@ -685,5 +778,31 @@ extern "C" int mk_fp8_quantize(const void* x, int64_t n, int32_t dtype, uint8_t*
     MK_LAUNCH((fp8_quant_kernel<float>), grid, block, 0, MK_ST, (const float*)x, (long)n, q, amax_ws,
               dequant_scale);
   } else return MK_ERR_UNSUPPORTED;
+  return mk_check_launch();
+}
+
+extern "C" int mk_fp8_quantize_rows(const void* x, int32_t rows, int32_t cols, int64_t ld, int32_t dtype,
+                                    uint8_t* q, int64_t ldq, float* scales, void* stream) {
+  if (!x || !q || !scales || rows <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
+  if (dtype != MK_BF16 || (cols % 8) || (ld % 8) || (ldq % 8) || (reinterpret_cast<uintptr_t>(x) & 15) ||
+      (reinterpret_cast<uintptr_t>(q) & 7))
+    return MK_ERR_UNSUPPORTED;
+  MK_LAUNCH(fp8_rowquant_kernel, dim3(rows), dim3(256), 0, MK_ST, (const bf16*)x, (long)ld, cols, q,
+            (long)ldq, scales);
+  return mk_check_launch();
+}
+
+extern "C" int mk_fp8_quantize_cols_t(const void* x, int32_t rows, int32_t cols, int64_t ld, int32_t dtype,
+                                      uint8_t* qt, int64_t ldqt, float* scales, float* amax_ws, void* stream) {
+  if (!x || !qt || !scales || !amax_ws || rows <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
+  if (dtype != MK_BF16 || (cols % 8) || (rows % 8) || (ld % 8) || (ldqt % 8) ||
+      (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(qt) & 7))
+    return MK_ERR_UNSUPPORTED;
+  MK_LAUNCH(fp8_zero_n_kernel, dim3(mk_cdiv(cols, 256)), dim3(256), 0, MK_ST, amax_ws, cols);
+  const int rpb = 128;
+  MK_LAUNCH(fp8_colamax_kernel, dim3(mk_cdiv(cols / 8, 256), mk_cdiv(rows, rpb)), dim3(256), 0, MK_ST,
+            (const bf16*)x, (long)ld, rows, cols, amax_ws, rpb);
+  MK_LAUNCH(fp8_quant_t_kernel, dim3(mk_cdiv(cols, 64), mk_cdiv(rows, 64)), dim3(256), 0, MK_ST,
+            (const bf16*)x, (long)ld, rows, cols, amax_ws, qt, (long)ldqt, scales);
   return mk_check_launch();
 }

@@ -1023,7 +1023,7 @@ namespace { int g_force_cfg = -1; }
 extern "C" int mk_gemm_set_cfg(int cfg) { g_force_cfg = cfg; return MK_OK; }
 
 namespace mkg {
-int launch_v7(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st);  // gemm_v7.hip
+int launch_v7(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st, bool fp8);  // gemm_v7.hip
 }
 
 // y[M <= 16, N] = prologue(x) W^T (+ residual): the linear layers of one decode position per sample
@@ -1129,6 +1129,8 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
   if (d->dtype != MK_F32 && d->dtype != MK_BF16) return MK_ERR_UNSUPPORTED;
   GemmArgs g;
   g.scale_a = d->scale_a; g.scale_b = d->scale_b;
+  g.scale_vec = (d->flags & MK_GEMM_SCALE_VEC) ? 1 : 0;
+  if (g.scale_vec && (!d->scale_a || !d->scale_b)) return MK_ERR_BAD_ARG;
   g.A = d->A; g.B = d->B; g.C = d->C; g.R = d->R; g.bias = d->bias;
   g.M = d->M; g.N = d->N; g.K = d->K;
   g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldr = d->ldr;
@@ -1185,7 +1187,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
                        (d->sB2 % 8 == 0) &&
                        (d->K % BK == 0 || (ktail_a && ktail_b && d->K > BK)) &&
                        fits(d->a_red_major, d->lda, BM) && fits(d->b_red_major, d->ldb, BN);
-    const bool v7_ok = v2_ok && !fp8 && d->K >= 128 && d->M > 128 && d->N > 128 &&
+    const bool v7_ok = v2_ok && d->K >= 128 && d->M > 128 && d->N > 128 &&
                        fits(d->a_red_major, d->lda, 256) && fits(d->b_red_major, d->ldb, 256);
     static const int n_cus = [] {
       int dev = 0, cus = 256;
@@ -1194,13 +1196,13 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
       return cus;
     }();
     int cfg;
-    if (fp8) cfg = 5;
-    else if (env_cfg >= 0) cfg = env_cfg;
+    if (env_cfg >= 0) cfg = env_cfg;
     else cfg = pick_cfg(d, nbatch, v7_ok, n_cus);
+    if (fp8 && cfg != 11) cfg = 5;        // fp8 exists on the two LDS-DMA tile kernels only
     if (cfg == 11 && !v7_ok) cfg = 5;
     if (cfg != 0 && cfg != 5 && cfg != 7 && cfg != 11) cfg = 5;
     if (cfg >= 5 && !v2_ok) cfg = 0;
-    if (fp8 && cfg != 5) return MK_ERR_UNSUPPORTED;
+    if (fp8 && cfg != 5 && cfg != 11) return MK_ERR_UNSUPPORTED;
     // Measured (profiles/): with BOTH operands reduction-major (dW = dy^T x) the global rows are
     // whole 256-B lines whatever BK is, and BK = 32 (32 KiB LDS -> 4 workgroups per CU) is 17 %
     // faster than BK = 64 on the 128x128 tile; K-major operands would degrade to 64-B segments.
@@ -1297,7 +1299,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     else MK_REG(AR, BR);                                     \
   } while (0)
     if (t256) {
-      const int rc = mkg::launch_v7(g, d->a_red_major != 0, d->b_red_major != 0, grid, st);
+      const int rc = mkg::launch_v7(g, d->a_red_major != 0, d->b_red_major != 0, grid, st, fp8);
       mkp::end(prof, st);
       return rc;
     }

@@ -13,7 +13,10 @@ struct GemmArgs {
   int nb2;
   long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
   float alpha;
-  const float* scale_a; const float* scale_b;  // optional device scalars multiplied into alpha (fp8)
+  const float* scale_a; const float* scale_b;  // optional device de-quantisation scales (fp8): scalars
+                                               // multiplied into alpha, or (scale_vec) one per row of A /
+                                               // per row of B = per output row / output column
+  int scale_vec;
   int bias_mode, act, accumulate;
   int tiles_m, tiles_n;
   int a_vec, b_vec;  // 1: 16-byte aligned vector loads allowed
@@ -73,8 +76,11 @@ MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* 
   constexpr int NPASS = 32 / RPI;   // passes per 32-row fragment
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   float alpha = g.alpha;
-  if (g.scale_a) alpha *= g.scale_a[0];
-  if (g.scale_b) alpha *= g.scale_b[0];
+  const bool svec = g.scale_vec != 0;
+  if (!svec) {
+    if (g.scale_a) alpha *= g.scale_a[0];
+    if (g.scale_b) alpha *= g.scale_b[0];
+  }
   __syncthreads();                  // every wave is done with the operand tiles in LDS
   float* buf = reinterpret_cast<float*>(smem) + w * 2048;
   const int srow = l & 31, sh = l >> 5;          // staging: this lane's accumulator row / half
@@ -83,6 +89,11 @@ MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* 
   const bool cols_full = ncol + 3 < g.N;
   // fast path: whole wave on aligned, in-range 4-column groups (always true off the N edge)
   const bool fast = g.c_vec && __all(cols_full ? 1 : 0);
+  float sb[4] = {1.f, 1.f, 1.f, 1.f};      // per-column de-quantisation scales (fp8, scale_vec)
+  if (svec) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sb[e] = alpha * g.scale_b[min(ncol + e, g.N - 1)];
+  }
   float bv[4] = {0.f, 0.f, 0.f, 0.f};
   if (g.bias_mode == 1) {
     const bf16* bp = reinterpret_cast<const bf16*>(g.bias);
@@ -115,6 +126,10 @@ MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* 
         const int row = p * RPI + rsub, m = mbase + p * RPI;
         const float4 t = *reinterpret_cast<const float4*>(buf + (row * W4 + (c4 ^ (row & (W4 - 1)))) * 4);
         float v[4] = {alpha * t.x, alpha * t.y, alpha * t.z, alpha * t.w};
+        if (svec) {
+          const float sa = g.scale_a[min(m, g.M - 1)];
+          v[0] = t.x * (sa * sb[0]); v[1] = t.y * (sa * sb[1]); v[2] = t.z * (sa * sb[2]); v[3] = t.w * (sa * sb[3]);
+        }
         if (g.bias_mode == 1) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bv[e];
@@ -156,7 +171,7 @@ MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* 
         for (int e = 0; e < 4; ++e) {
           const int n = ncol + e;
           if (n >= g.N) continue;
-          float x = alpha * tv[e];
+          float x = svec ? tv[e] * (g.scale_a[m] * sb[e]) : alpha * tv[e];
           if (g.bias_mode == 1) x += bv[e];
           else if (g.bias_mode == 2) x += bm;
           if (g.act) x = apply_act(x, g.act);

@@ -114,7 +114,7 @@ MK_DEV void v7_read_offsets(int base_row, int l, int (&off)[4]) {
 // ---- spatial tail: one 128 x 128 sub-tile (quadrant `sub & 3` of tail tile `sub >> 2`) over the
 // full K.  8 waves = 2 (M) x 4 (N) of 64 x 32; a stage = one A and one B half-tile image (32 KiB),
 // five stages, LDS-DMA four K-tiles ahead, one barrier and one counted vmcnt per K-tile.
-template <bool A_RED, bool B_RED>
+template <bool A_RED, bool B_RED, bool FP8 = false>
 MK_DEV void v7_subtile(const GemmArgs& g, int sub) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 2 * HALF_BYTES;
@@ -197,11 +197,29 @@ MK_DEV void v7_subtile(const GemmArgs& g, int sub) {
       FA[1][ks] = V7_FRAG(A_RED, aad, 1, ks);                                  \
     }                                                                          \
   } while (0)
+#define V7S_CAT(LO, HI)                                                        \
+  [&]() -> i32x8 {                                                             \
+    const i32x4 lo_ = __builtin_bit_cast(i32x4, LO), hi_ = __builtin_bit_cast(i32x4, HI); \
+    i32x8 r_;                                                                  \
+    r_[0] = lo_[0]; r_[1] = lo_[1]; r_[2] = lo_[2]; r_[3] = lo_[3];            \
+    r_[4] = hi_[0]; r_[5] = hi_[1]; r_[6] = hi_[2]; r_[7] = hi_[3];            \
+    return r_;                                                                 \
+  }()
 #define V7S_MMA(FA, FB)                                                        \
   do {                                                                         \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                         \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks], FA[0][ks], acc[0][0], 0, 0, 0); \
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks], FA[1][ks], acc[1][0], 0, 0, 0); \
+    if constexpr (FP8) {                                                       \
+      _Pragma("unroll") for (int kp = 0; kp < 2; ++kp) {                       \
+        const i32x8 b8_ = V7S_CAT(FB[2 * kp], FB[2 * kp + 1]);                 \
+        acc[0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(           \
+            b8_, V7S_CAT(FA[0][2 * kp], FA[0][2 * kp + 1]), acc[0][0], 0, 0, 0, 127, 0, 127); \
+        acc[1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(           \
+            b8_, V7S_CAT(FA[1][2 * kp], FA[1][2 * kp + 1]), acc[1][0], 0, 0, 0, 127, 0, 127); \
+      }                                                                        \
+    } else {                                                                   \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                       \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks], FA[0][ks], acc[0][0], 0, 0, 0); \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks], FA[1][ks], acc[1][0], 0, 0, 0); \
+      }                                                                        \
     }                                                                          \
     asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][0]));                       \
   } while (0)
@@ -228,13 +246,15 @@ MK_DEV void v7_subtile(const GemmArgs& g, int sub) {
   }
 #undef V7S_STEP
 #undef V7S_MMA
+#undef V7S_CAT
 #undef V7S_READ
 #undef V7S_WAIT
   wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0, smem);
 }
 
-template <bool A_RED, bool B_RED>
+template <bool A_RED, bool B_RED, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_v7_kernel(GemmArgs g) {
+  static_assert(!FP8 || (!A_RED && !B_RED), "fp8 operands are K-major");
   constexpr int FM = 4, FN = 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
@@ -242,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v7_kernel(GemmArgs g) {
   {
     const int bid = blockIdx.x;
     if (bid >= g.dp_tiles) {          // spatial tail: quadrant (bid' & 3) of tail tile (bid' >> 2)
-      v7_subtile<A_RED, B_RED>(g, xcd_remap(bid - g.dp_tiles, (int)gridDim.x - g.dp_tiles));
+      v7_subtile<A_RED, B_RED, FP8>(g, xcd_remap(bid - g.dp_tiles, (int)gridDim.x - g.dp_tiles));
       return;
     }
     tile_from_index(xcd_remap(bid, g.dp_tiles), g.tiles_m, g.tiles_n, tm, tn, 8);
@@ -316,11 +336,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v7_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);         \
   } while (0)
 // 8 MFMAs: rows I0, I0+1 (fragments held in fa_) x column fragment J (held in FB)
+// fp8 (e4m3) operands, FP8 = true: the tile bytes, the LDS image and the 16-byte fragment reads are
+// those of the bf16 kernel (GemmArgs in 2-byte units, K-major operands only); two consecutive reads
+// are concatenated into the 32-byte operand of ONE v_mfma_scale_f32_32x32x64_f8f6f4 (64 fp8 k-slots,
+// scales 2^0: the de-quantisation scales are applied in the epilogue; any k-slot permutation is
+// legal because A and B use the same one).  Same instruction-issue time per K-tile, twice the K.
+#define V7_CAT(LO, HI)                                                                            \
+  [&]() -> i32x8 {                                                                                \
+    const i32x4 lo_ = __builtin_bit_cast(i32x4, LO), hi_ = __builtin_bit_cast(i32x4, HI);         \
+    i32x8 r_;                                                                                     \
+    r_[0] = lo_[0]; r_[1] = lo_[1]; r_[2] = lo_[2]; r_[3] = lo_[3];                               \
+    r_[4] = hi_[0]; r_[5] = hi_[1]; r_[6] = hi_[2]; r_[7] = hi_[3];                               \
+    return r_;                                                                                    \
+  }()
 #define V7_MMA(I0, J, FB)                                                                         \
   do {                                                                                            \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                         \
-      acc[I0][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks_], fa_[0][ks_], acc[I0][J], 0, 0, 0); \
-      acc[I0 + 1][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks_], fa_[1][ks_], acc[I0 + 1][J], 0, 0, 0); \
+    if constexpr (FP8) {                                                                          \
+      _Pragma("unroll") for (int kp_ = 0; kp_ < 2; ++kp_) {                                       \
+        const i32x8 b8_ = V7_CAT(FB[2 * kp_], FB[2 * kp_ + 1]);                                   \
+        acc[I0][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                             \
+            b8_, V7_CAT(fa_[0][2 * kp_], fa_[0][2 * kp_ + 1]), acc[I0][J], 0, 0, 0, 127, 0, 127); \
+        acc[I0 + 1][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                         \
+            b8_, V7_CAT(fa_[1][2 * kp_], fa_[1][2 * kp_ + 1]), acc[I0 + 1][J], 0, 0, 0, 127, 0, 127); \
+      }                                                                                           \
+    } else {                                                                                      \
+      _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                       \
+        acc[I0][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks_], fa_[0][ks_], acc[I0][J], 0, 0, 0); \
+        acc[I0 + 1][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks_], fa_[1][ks_], acc[I0 + 1][J], 0, 0, 0); \
+      }                                                                                           \
     }                                                                                             \
     /* register-only MFMAs are otherwise sunk / hoisted across the barriers (s5.7 item 3) */      \
     asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I0 + 1][J]));                                    \
@@ -405,28 +448,30 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v7_kernel(GemmArgs g) {
   if (wr == 0) V7_BAR();       // re-align the two halves
 #undef V7_TILE
 #undef V7_MMA
+#undef V7_CAT
 #undef V7_BAR
 
   wave_epilogue(acc, g, C, Rp, m0, n0, wm0, wn0, smem);
 }
 
-template <bool A_RED, bool B_RED>
+template <bool A_RED, bool B_RED, bool FP8 = false>
 int launch(const GemmArgs& g, dim3 grid, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v7_kernel<A_RED, B_RED>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v7_kernel<A_RED, B_RED, FP8>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS7) != hipSuccess)
       return MK_ERR_LAUNCH;
     attr_done = true;
   }
-  MK_LAUNCH((gemm_bf16_v7_kernel<A_RED, B_RED>), grid, dim3(512), LDS7, st, g);
+  MK_LAUNCH((gemm_bf16_v7_kernel<A_RED, B_RED, FP8>), grid, dim3(512), LDS7, st, g);
   return mk_check_launch();
 }
 
 }  // namespace
 
 namespace mkg {
-int launch_v7(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st) {
+int launch_v7(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st, bool fp8) {
+  if (fp8) return (a_red || b_red) ? MK_ERR_UNSUPPORTED : launch<false, false, true>(g, grid, st);
   if (!a_red && !b_red) return launch<false, false>(g, grid, st);
   if (!a_red && b_red) return launch<false, true>(g, grid, st);
   if (a_red && !b_red) return launch<true, false>(g, grid, st);

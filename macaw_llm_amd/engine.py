@@ -85,22 +85,44 @@ def attention_bwd(do: TDesc, q: TDesc, k: TDesc, v: TDesc, probs, pd, dq: TDesc,
                  sA=sP, sB=(q.bs, hd), sC=(dk.bs, hd), b_off=q.off, c_off=dk.off)
 
 
-# BASELINE cfg 5: "fp8 MFMA for alignment-attn and QKV GEMMs".  Opt-in (MM_LLMs.set_fp8): the
-# FORWARD of the fused q|k|v projection and of the alignment K/V projection of the token table
-# runs on the f8f6f4 MFMA with per-tensor e4m3 scales (activations and weights quantised on the
-# device each step); the backward stays bf16 on the bf16 operands (straight-through).
-FP8 = {"qkv": False, "align": False}
-
-
-def _fp8_linear(x, W, bias=None):
-    xq, sx = ops.quantize_fp8(x)
-    wq, sw = ops.quantize_fp8(W)
-    return ops.linear_fp8(xq, sx, wq, sw, bias=bias)
+# BASELINE cfg 5: "fp8 MFMA for alignment-attn and QKV GEMMs".  Opt-in (MM_LLMs.set_fp8): the FORWARD
+# and the GRAD-INPUT GEMMs of the fused q|k|v projection (modeling.py:159-162) and of the alignment
+# K/V projection of the token table (:882-910) run on the f8f6f4 MFMA at twice the bf16 rate:
+#   * activations / gradients: e4m3 with ONE SCALE PER ROW (token), quantised where they are produced;
+#   * weights: e4m3 with one scale per output channel (forward) and, as a transposed copy, one scale
+#     per input channel (grad-input), made ONCE per optimizer step (ops.fp8_weight) and reused by the
+#     checkpoint recompute;
+#   * grad-weight GEMMs stay bf16 (they reduce over tokens: both operands would need transposed 8-bit
+#     copies per step for a GEMM that is a third of the projection's work).
+# "mlp" extends the same treatment to gate|up and down (beyond BASELINE cfg 5's wording; off unless asked).
+FP8 = {"qkv": False, "align": False, "mlp": False}
 
 
 def _fp8_ok(x, W) -> bool:
-    return (x.dtype == torch.bfloat16 and x.shape[1] % 128 == 0 and x.is_contiguous()
-            and W.is_contiguous())
+    """x [M, K] bf16 rows, W [N, K]: fp8 needs K % 128 (MFMA k-slots) and 16-byte aligned pitches"""
+    return (x.dim() == 2 and x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and x.shape[1] % 128 == 0
+            and x.stride(1) == 1 and x.stride(0) % 8 == 0 and W.is_contiguous() and W.shape[0] % 8 == 0)
+
+
+def _fp8_linear(x, W, bias=None, residual=None, out=None):
+    """y = x W^T (+ bias, + residual) with e4m3 operands: per-token scales for x, per-output-channel
+    scales for W (cached per optimizer step)"""
+    xq, sx = ops.quantize_fp8_rows(x)
+    wq, sw = ops.fp8_weight(W)
+    return ops.linear_fp8(xq, sx, wq, sw, bias=bias, residual=residual, out=out)
+
+
+def _fp8_dx_ok(dy, W) -> bool:
+    """dy [M, N] bf16 rows, W [N, K]: the reduction runs over N"""
+    return (dy.dim() == 2 and dy.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and dy.shape[1] % 128 == 0
+            and dy.stride(1) == 1 and dy.stride(0) % 8 == 0 and W.is_contiguous() and W.shape[1] % 8 == 0)
+
+
+def _fp8_dx(dy, W, out=None, accumulate=False):
+    """dx = dy W with e4m3 operands: per-token scales for dy, W^T K-major with per-input-channel scales"""
+    dq, sd = ops.quantize_fp8_rows(dy)
+    wt, st = ops.fp8_weight(W, transposed=True)
+    return ops.linear_fp8(dq, sd, wt, st, out=out, accumulate=accumulate)
 
 
 def flash_ok(dtype, hd) -> bool:
@@ -167,15 +189,19 @@ class LlamaLayerFn(torch.autograd.Function):
                                      1.0 / math.sqrt(hd), kmask=kmask, causal=True)
         h1 = ops.linear_fwd(att, wo, residual=x2)
         _, y2, rstd2 = ops.rmsnorm_fwd(h1, ln2, eps)
+        fp8_mlp = FP8["mlp"] and wgu is not None and _fp8_ok(y2, wgu) and _fp8_dx_ok(y2, wd)
         if wgu is not None:
-            gu = ops.linear_fwd(y2, wgu)                      # [M, 2FF] = [gate | up]
+            gu = _fp8_linear(y2, wgu) if fp8_mlp else ops.linear_fwd(y2, wgu)     # [M, 2FF] = [gate | up]
             a = ops.swiglu2d_fwd(gu, FF)
             g = u = None
         else:
             g, u = ops.linear_fwd(y2, wg), ops.linear_fwd(y2, wu)
             a = ops.swiglu_fwd(g, u)
             gu = None
-        out = ops.linear_fwd(a, wd, residual=h1)
+        if wgu is not None and fp8_mlp and _fp8_ok(a, wd):
+            out = _fp8_linear(a, wd, residual=h1)
+        else:
+            out = ops.linear_fwd(a, wd, residual=h1)
         return out, (rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, gu, a), use_flash
 
     @staticmethod
@@ -214,13 +240,14 @@ class LlamaLayerFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dout2 = _c2(dout, M, D)
         # ---- MLP
-        da = ops.linear_dx(dout2, wd)
+        fp8_mlp = FP8["mlp"] and gu is not None and _fp8_dx_ok(dout2, wd) and _fp8_ok(y2, wgu)
+        da = _fp8_dx(dout2, wd) if fp8_mlp else ops.linear_dx(dout2, wd)
         dwd = ops.linear_dw(dout2, a, w=wd) if need[13] else None
         dwg = dwu = None
         if gu is not None:
             dgu = ops.swiglu2d_bwd(gu, da, FF)
             del da
-            dy2 = ops.linear_dx(dgu, wgu)
+            dy2 = _fp8_dx(dgu, wgu) if (fp8_mlp and _fp8_dx_ok(dgu, wgu)) else ops.linear_dx(dgu, wgu)
             if need[11] or need[12]:
                 dwgu = ops.linear_dw(dgu, y2, w=wgu)           # [2FF, D]
                 dwg, dwu = dwgu[:FF], dwgu[FF:]
@@ -259,7 +286,10 @@ class LlamaLayerFn(torch.autograd.Function):
             ops.rope_(dk, cos, sin, pos, H, hd, inverse=True)
         dwq = dwk = dwv = None
         if wqkv is not None:
-            dy1 = ops.linear_dx(dqkv, wqkv)
+            if FP8["qkv"] and _fp8_dx_ok(dqkv, wqkv) and _fp8_ok(y1, wqkv):
+                dy1 = _fp8_dx(dqkv, wqkv)                      # e4m3 dy x e4m3 W^T (cfg 5)
+            else:
+                dy1 = ops.linear_dx(dqkv, wqkv)
             if need[7] or need[8] or need[9]:
                 dwqkv = ops.linear_dw(dqkv, y1, w=wqkv)        # [3D, D]
                 dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]
@@ -663,10 +693,8 @@ def _align_fwd(feats, E, prm, heads, kw, stride, p, seed):
     Lk = V + 2
     Lkp = _pad64(Lk)   # rows [V+1, Lkp) are zero: the add_zero_attn row + alignment padding
     kv = torch.empty((Lkp, 2 * D), dtype=feats.dtype, device=feats.device)
-    if FP8["align"] and _fp8_ok(E, in_w):
-        eq, se = ops.quantize_fp8(E)
-        wq8, sw8 = ops.quantize_fp8(in_w[D:])
-        ops.linear_fp8(eq, se, wq8, sw8, bias=in_b[D:], out=kv[:V])
+    if FP8["align"] and _fp8_ok(E, in_w[D:]):
+        _fp8_linear(E, in_w[D:], bias=in_b[D:], out=kv[:V])
     else:
         ops.gemm_raw(E, in_w, kv, V, 2 * D, D, D, D, 2 * D, bias=in_b[D:], bias_mode=1, b_off=D * D)
     ops.copy2d(bias_k, kv, 1, D, D, 2 * D, dst_off=V * 2 * D)
@@ -702,7 +730,10 @@ def _align_bwd(da, E, dE, dE_init, prm, saved, dims, need_feats):
     g["bias_k"], g["bias_v"] = brow[0, :D].reshape(1, 1, D), brow[0, D:].reshape(1, 1, D)
     dkvt = dkv[:V]
     # table gradient: dE (+)= dKV W_kv
-    ops.linear_dx(dkvt, in_w[D:], out=dE, accumulate=not dE_init)
+    if FP8["align"] and _fp8_dx_ok(dkvt, in_w[D:]) and _fp8_ok(E, in_w[D:]):
+        _fp8_dx(dkvt, in_w[D:], out=dE, accumulate=not dE_init)
+    else:
+        ops.linear_dx(dkvt, in_w[D:], out=dE, accumulate=not dE_init)
     din_w = ops.grad_dst(in_w)              # (a registered gradient-bucket slot, else a fresh tensor)
     if din_w is None:
         din_w = torch.empty_like(in_w)

@@ -19,7 +19,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libmacaw_hip.so"
 
 MK_F32, MK_BF16, MK_F16, MK_FP8 = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _ERR = {-1: "MK_ERR_BAD_ARG", -2: "MK_ERR_UNSUPPORTED", -3: "MK_ERR_LAUNCH"}
 
@@ -108,6 +108,8 @@ SIGNATURES = {
                  _vp],
     "mk_adamw_multi": [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _i32, _vp],
     "mk_fp8_quantize": [_vp, _i64, _i32, _vp, _vp, _vp, _vp],
+    "mk_fp8_quantize_rows": [_vp, _i32, _i32, _i64, _i32, _vp, _i64, _vp, _vp],
+    "mk_fp8_quantize_cols_t": [_vp, _i32, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mk_image_transform": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp],
     "mk_log_mel": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp],
 }

@@ -748,12 +748,16 @@ class MM_LLMs(PreTrainedModel):
         return self.llm(inputs_embeds=text_embeddings, attention_mask=attention_mask, labels=labels)
 
     @staticmethod
-    def set_fp8(qkv: bool = True, align: bool = True):
-        """BASELINE cfg 5: run the forward of the fused q|k|v projections and of the alignment
-        K/V projection of the token table on the fp8 (e4m3, per-tensor scale) MFMA path.  Needs
-        bf16 parameters and fused projections (LlamaDecoderLayer.fuse_projections); layers that
-        do not qualify keep the bf16 GEMM.  Process-wide switch."""
-        eng.FP8["qkv"], eng.FP8["align"] = bool(qkv), bool(align)
+    def set_fp8(qkv: bool = True, align: bool = True, mlp: bool = False):
+        """BASELINE cfg 5: run the forward AND grad-input GEMMs of the fused q|k|v projections
+        (modeling.py:159-162) and of the alignment K/V projection of the token table (:882-910) on
+        the fp8 MFMA path: e4m3, one scale per token row for activations / gradients, one per
+        channel for the weights, which are quantised once per optimizer step (engine.FP8).
+        mlp=True extends it to gate|up / down (not part of cfg 5's wording).  Needs bf16
+        parameters and fused projections; layers that do not qualify keep the bf16 GEMM.
+        Process-wide switch."""
+        eng.FP8["qkv"], eng.FP8["align"], eng.FP8["mlp"] = bool(qkv), bool(align), bool(mlp)
+        ops.clear_fp8_cache()
 
     def prepare_inputs_for_generation(self, inputs):
         """modeling.py:965-1048 — same outputs (inputs_embeds, attention_mask, labels)."""

@@ -116,14 +116,73 @@ def quantize_fp8(x):
     return q, ws[1:2]
 
 
-def linear_fp8(xq, sx, wq, sw, bias=None, act=0, residual=None, out=None):
-    """out[M, N] (bf16) = act((xq . wq^T) * sx * sw + bias) + residual with fp8 operands xq [M, K],
-    wq [N, K] (uint8 e4m3 bytes) and their device de-quantisation scales sx, sw (f32[1])."""
+def quantize_fp8_rows(x, out=None):
+    """per-ROW scaled OCP e4m3 of a row-major bf16 matrix [rows, cols] (pitched rows allowed):
+    returns (q uint8 [rows, cols], scales f32 [rows]); q[r] = e4m3(x[r] * 448 / amax_r), scales[r] =
+    amax_r / 448.  One scale per token (activations, gradients) / per output channel (weights)."""
+    lib = _L.load()
+    rows, cols = x.shape
+    q = out if out is not None else torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _L.check(lib.mk_fp8_quantize_rows(_p(x), rows, cols, _rowmajor(x), dt(x), _p(q), _rowmajor(q), _p(sc), _st()),
+             "mk_fp8_quantize_rows")
+    return q, sc
+
+
+def quantize_fp8_cols_t(W):
+    """per-COLUMN scaled e4m3 of W [rows, cols], written TRANSPOSED: returns (qt uint8 [cols, rows],
+    scales f32 [cols]) -- W^T K-major for the fp8 grad-input GEMM dx = dy W (one scale per input
+    channel)."""
+    lib = _L.load()
+    rows, cols = W.shape
+    qt = torch.empty((cols, rows), dtype=torch.uint8, device=W.device)
+    sc = torch.empty(cols, dtype=torch.float32, device=W.device)
+    ws = torch.empty(cols, dtype=torch.float32, device=W.device)
+    _L.check(lib.mk_fp8_quantize_cols_t(_p(W), rows, cols, _rowmajor(W), dt(W), _p(qt), rows, _p(sc), _p(ws), _st()),
+             "mk_fp8_quantize_cols_t")
+    return qt, sc
+
+
+# fp8 copies of weights are made ONCE per optimizer step, not per call: (data_ptr, shape, kind) ->
+# (weight version, torch version counter, q, scales).  The optimizer runtimes bump WEIGHT_VERSION after
+# every update (bucketed.BucketedStep.finish, optim.FusedAdamW.step*); torch-side in-place edits
+# (load_state_dict, manual .copy_) move the tensor's own version counter.
+WEIGHT_VERSION = [0]
+_W8 = {}
+
+
+def bump_weight_version():
+    WEIGHT_VERSION[0] += 1
+
+
+def fp8_weight(W, transposed=False):
+    """cached e4m3 copy of weight W [N, K]: rows scaled (q [N, K], scales [N]) for y = x W^T, or
+    transposed / column scaled (qt [K, N], scales [K]) for dx = dy W"""
+    key = (W.data_ptr(), tuple(W.shape), W.stride(0), transposed)
+    ver = (WEIGHT_VERSION[0], W._version)
+    ent = _W8.get(key)
+    if ent is None or ent[0] != ver:
+        q, sc = quantize_fp8_cols_t(W) if transposed else quantize_fp8_rows(W)
+        ent = _W8[key] = (ver, q, sc)
+    return ent[1], ent[2]
+
+
+def clear_fp8_cache():
+    _W8.clear()
+
+
+def linear_fp8(xq, sx, wq, sw, bias=None, act=0, residual=None, out=None, accumulate=False):
+    """out[M, N] (bf16) = act((xq . wq^T) * sx * sw + bias) + residual (+ out) with fp8 operands xq
+    [M, K], wq [N, K] (uint8 e4m3 bytes, K-major) and their device de-quantisation scales: f32[1]
+    per-tensor scalars, or f32[M] / f32[N] per-row vectors (quantize_fp8_rows / fp8_weight)."""
     lib = _L.load()
     M, K = xq.shape
     N = wq.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=xq.device)
+    vec = sx.numel() > 1 or sw.numel() > 1
+    if vec and (sx.numel() != M or sw.numel() != N):
+        raise MacawHipError(f"linear_fp8: scale vectors {sx.numel()} / {sw.numel()} for a {M} x {N} output")
     d = GemmDesc()
     d.A, d.B, d.C = _p(xq), _p(wq), _p(out)
     d.R = _p(residual) if residual is not None else None
@@ -135,7 +194,9 @@ def linear_fp8(xq, sx, wq, sw, bias=None, act=0, residual=None, out=None):
     d.alpha = 1.0
     d.bias_mode = 1 if bias is not None else 0
     d.act = act
+    d.accumulate = int(accumulate)
     d.dtype = MK_FP8
+    d.flags = 4 if vec else 0            # MK_GEMM_SCALE_VEC
     ws = _workspace(xq.device)
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
     d.scale_a, d.scale_b = _p(sx), _p(sw)

@@ -54,6 +54,7 @@ class FusedAdamW:
         (used by train.OverlappedStep from gradient hooks)"""
         if p.grad is None:
             return
+        ops.bump_weight_version()
         b1, b2 = self.betas
         master, m, v = self._state(p)
         g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
@@ -84,6 +85,7 @@ class FusedAdamW:
         per dtype (same arithmetic as step_param; the pointer table is rebuilt each step because
         autograd allocates fresh gradients)."""
         from . import lib as _L
+        ops.bump_weight_version()
         groups = {}
         keep = []
         for p in params:
@@ -268,6 +270,7 @@ class FusedAdamW:
         from `grad_shard`, the rank-averaged gradient of exactly those elements.  Optimizer
         state (fp32 master / m / v, 12 B per owned element) exists only for the slice and is
         keyed by `key` (stable across steps: the slice a rank owns never changes)."""
+        ops.bump_weight_version()
         b1, b2 = self.betas
         master, m, v = self._shard_state(key, w)
         ops.adamw_(w, master, m, v, grad_shard, self.lr, b1, b2, self.eps, self.weight_decay,

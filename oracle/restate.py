@@ -26,6 +26,19 @@ import torch.nn.functional as F
 
 SD = Dict[str, torch.Tensor]
 
+# Test hook (tests/fp8_ref.py): the "what does the e4m3 FORMAT itself cost" yardstick for the fp8
+# path of BASELINE cfg 5 swaps a fake-quantised linear in at the sites the fp8 MFMA path covers --
+# "qkv" (modeling.py:179-181), "align" (the K/V projection of the token table, :882-910), "mlp"
+# (:139-140).  None / empty = plain F.linear everywhere, i.e. the reference's arithmetic.
+FP8_LINEAR = None
+FP8_SITES = ()
+
+
+def _lin(x, W, b=None, site=""):
+    if FP8_LINEAR is not None and site in FP8_SITES:
+        return FP8_LINEAR(x, W, b)
+    return F.linear(x, W, b)
+
 
 # ------------------------------------------------------------------ LLaMA ---
 def rms_norm(x, w, eps):
@@ -78,9 +91,9 @@ def llama_attention(sd: SD, p: str, x, mask, position_ids, n_heads, cos, sin):
     """modeling.py:168-231 (LlamaAttention.forward, no KV cache)."""
     B, S, D = x.shape
     hd = D // n_heads
-    q = F.linear(x, sd[p + "q_proj.weight"]).view(B, S, n_heads, hd).transpose(1, 2)
-    k = F.linear(x, sd[p + "k_proj.weight"]).view(B, S, n_heads, hd).transpose(1, 2)
-    v = F.linear(x, sd[p + "v_proj.weight"]).view(B, S, n_heads, hd).transpose(1, 2)
+    q = _lin(x, sd[p + "q_proj.weight"], site="qkv").view(B, S, n_heads, hd).transpose(1, 2)
+    k = _lin(x, sd[p + "k_proj.weight"], site="qkv").view(B, S, n_heads, hd).transpose(1, 2)
+    v = _lin(x, sd[p + "v_proj.weight"], site="qkv").view(B, S, n_heads, hd).transpose(1, 2)
     q, k = apply_rope(q, k, cos.to(x.dtype), sin.to(x.dtype), position_ids)
     w = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(hd)
     if mask is not None:
@@ -93,8 +106,8 @@ def llama_attention(sd: SD, p: str, x, mask, position_ids, n_heads, cos, sin):
 
 def llama_mlp(sd: SD, p: str, x):
     """modeling.py:139-140."""
-    return F.linear(F.silu(F.linear(x, sd[p + "gate_proj.weight"])) * F.linear(x, sd[p + "up_proj.weight"]),
-                    sd[p + "down_proj.weight"])
+    return _lin(F.silu(_lin(x, sd[p + "gate_proj.weight"], site="mlp")) * _lin(x, sd[p + "up_proj.weight"], site="mlp"),
+                sd[p + "down_proj.weight"], site="mlp")
 
 
 def llama_layer(sd: SD, p: str, x, mask, position_ids, n_heads, eps, cos, sin):
@@ -165,9 +178,9 @@ def mha_forward_hoisted(sd: SD, p: str, query, table, n_heads):
     hd = E // n_heads
     W, b = sd[p + "in_proj_weight"], sd[p + "in_proj_bias"]
     q = F.linear(query, W[:E], b[:E])
-    k = torch.cat([F.linear(table, W[E:2 * E], b[E:2 * E]), sd[p + "bias_k"].view(1, E),
+    k = torch.cat([_lin(table, W[E:2 * E], b[E:2 * E], site="align"), sd[p + "bias_k"].view(1, E),
                    torch.zeros(1, E, dtype=table.dtype, device=table.device)], dim=0)
-    v = torch.cat([F.linear(table, W[2 * E:], b[2 * E:]), sd[p + "bias_v"].view(1, E),
+    v = torch.cat([_lin(table, W[2 * E:], b[2 * E:], site="align"), sd[p + "bias_v"].view(1, E),
                    torch.zeros(1, E, dtype=table.dtype, device=table.device)], dim=0)
     S2 = k.shape[0]
     qh = q.reshape(L * B, n_heads, hd).transpose(0, 1)        # [H, L*B, hd]

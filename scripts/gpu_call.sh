@@ -13,11 +13,21 @@ for step in "$@"; do
       timeout 300 python scripts/probe/gloo_cuda_race.py 150 0 > $out/gloo_probe_idle.txt 2>&1
       timeout 400 python scripts/probe/gloo_cuda_race.py 150 1 > $out/gloo_probe_burner.txt 2>&1 ;;
     tests)
-      timeout 1500 python -m pytest tests -m gpu -q -rf --timeout 900 -p no:cacheprovider > $out/tests.log 2>&1
+      timeout 900 python -m pytest tests -m gpu -q -rf --timeout 240 --durations=12 -p no:cacheprovider > $out/tests.log 2>&1
       echo "pytest rc=$?" >> $out/tests.log ;;
     tests_s)
-      timeout 1500 python -m pytest tests -m gpu -q -rf -s --timeout 900 -p no:cacheprovider > $out/tests.log 2>&1
+      timeout 900 python -m pytest tests -m gpu -q -rf -s --timeout 240 --durations=12 -p no:cacheprovider > $out/tests.log 2>&1
       echo "pytest rc=$?" >> $out/tests.log ;;
+    tests_fast)   # everything but the full-size file
+      timeout 600 python -m pytest tests -m gpu -q -rf -s --timeout 240 --durations=12 -p no:cacheprovider \
+        --ignore=tests/test_fullsize_gpu.py > $out/tests_fast.log 2>&1
+      echo "pytest rc=$?" >> $out/tests_fast.log ;;
+    cfg5)
+      timeout 400 python bench.py --config 5 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_cfg5_fp8.json 2> $out/bench_cfg5_fp8.err
+      timeout 400 python bench.py --config 5 --steps 4 --warmup 2 --no-cpu-baseline --no-fp8 > $out/bench_cfg5_bf16.json 2> $out/bench_cfg5_bf16.err
+      timeout 400 python bench.py --config 5 --steps 4 --warmup 2 --no-cpu-baseline --fp8-mlp > $out/bench_cfg5_fp8mlp.json 2> $out/bench_cfg5_fp8mlp.err ;;
+    cfg4)
+      timeout 400 python bench.py --config 4 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_cfg4.json 2> $out/bench_cfg4.err ;;
     bench)
       timeout 600 python bench.py --steps 8 --warmup 3 > $out/bench_cfg3.json 2> $out/bench_cfg3.err ;;
     flaky)
@@ -26,5 +36,5 @@ for step in "$@"; do
   esac
   echo "$step: $(( $(date +%s) - t0 )) s" >> $out/timing.txt
 done
-tail -5 $out/tests.log 2>/dev/null
+tail -5 $out/tests*.log 2>/dev/null
 cat $out/timing.txt

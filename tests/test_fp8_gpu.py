@@ -1,4 +1,4 @@
-"""GPU: fp8 (OCP e4m3, per-tensor scale) quantisation and the f8f6f4-MFMA GEMM of BASELINE cfg 5
+"""GPU: fp8 (OCP e4m3; per-tensor, per-row and per-channel scales) quantisation and the f8f6f4-MFMA GEMMs of BASELINE cfg 5
 ("fp8 MFMA for alignment-attn and QKV GEMMs").
   * quantisation is byte-exact against torch's float8_e4m3fn cast of the same scaled values;
   * the GEMM is checked against an fp32 matmul of the DE-QUANTISED operands (fp8 products are
@@ -65,13 +65,103 @@ def test_fp8_gemm_rejects_what_it_cannot_do(dev):
         ops.linear_fp8(x, s, x, s)
 
 
-def test_model_with_fp8_qkv_and_alignment(dev):
-    """MM_LLMs.set_fp8 (BASELINE cfg 5): same weights and inputs through the bf16 engine and through
-    the fp8 forward of q|k|v and of the alignment K/V projection.  e4m3 carries 3 mantissa bits, so
-    the logits move by a few percent of their range (bound 8 %), the loss by < 5 %; the backward is
-    the bf16 straight-through one and must stay finite and close in norm."""
+def test_fp8_row_and_transposed_column_quantisation_byte_exact(dev):
+    """mk_fp8_quantize_rows (one scale per row) and mk_fp8_quantize_cols_t (one scale per column,
+    transposed output) against the torch restatement of the same arithmetic, byte for byte"""
+    from fp8_ref import quant_rows_bytes
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(300, 256, generator=g) * torch.logspace(-3, 2, 300)[:, None]).to(torch.bfloat16)
+    x[7] = 0                                                   # all-zero row: scale 1, zeros
+    x[11, 5] = 3000.0
+    q, s = ops.quantize_fp8_rows(x.to(dev))
+    qr, sr = quant_rows_bytes(x)
+    assert torch.equal(q.cpu(), qr) and torch.equal(s.cpu(), sr)
+    assert s[7].item() == 1.0 and not q[7].any()
+    # pitched input (a column slice of a wider buffer), as the engine passes views
+    wide = torch.zeros(300, 512, dtype=torch.bfloat16)
+    wide[:, 128:384] = x
+    q2, s2 = ops.quantize_fp8_rows(wide.to(dev)[:, 128:384])
+    assert torch.equal(q2.cpu(), qr) and torch.equal(s2.cpu(), sr)
+    W = (torch.randn(320, 192, generator=g) * 0.05).to(torch.bfloat16)
+    W[:, 9] = 0
+    qt, st = ops.quantize_fp8_cols_t(W.to(dev))
+    qtr, str_ = quant_rows_bytes(W.t().contiguous())
+    assert qt.shape == (192, 320)
+    assert torch.equal(qt.cpu(), qtr) and torch.equal(st.cpu(), str_)
+
+
+@pytest.mark.parametrize("M,N,K", [(4608, 12288, 4096), (4608, 4096, 12288), (4608, 15360, 5120), (1000, 4096, 1024),
+                                   (200, 136, 256)])
+def test_fp8_gemm_with_per_row_scales_on_both_tile_kernels(dev, M, N, K):
+    """row-scaled operands (MK_GEMM_SCALE_VEC) through mk_gemm: the 256 x 256 v7 kernel with the
+    f8f6f4 MFMA for the big shapes (q|k|v forward and grad-input at 7B / 13B), the 128 x 128 kernel
+    for the small ones -- against an fp32 matmul of the DE-QUANTISED operands (the kernel adds only
+    accumulation order + the bf16 output rounding) and against the unquantised product (the format)"""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * torch.logspace(-2, 1, M)[:, None]).to(torch.bfloat16).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.02 * (1 + torch.arange(N) % 7)[:, None]).to(torch.bfloat16).to(dev)
+    xq, sx = ops.quantize_fp8_rows(x)
+    wq, sw = ops.quantize_fp8_rows(W)
+    y = ops.linear_fp8(xq, sx, wq, sw).float()
+    deq = lambda q, s_: q.view(torch.float8_e4m3fn).float() * s_[:, None]     # noqa: E731
+    ref = deq(xq, sx) @ deq(wq, sw).t()
+    assert torch.isfinite(y).all()
+    rowmax = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-20)
+    assert ((y - ref).abs() / rowmax).max().item() <= 8e-3          # per row: rows span 3 decades
+    full = x.float() @ W.float().t()
+    assert ((y - full).abs() / full.abs().amax(dim=1, keepdim=True)).max().item() <= 4e-2
+    # accumulate + residual epilogue (the dE accumulation of the alignment backward)
+    r = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev)
+    out = r.clone()
+    ops.linear_fp8(xq, sx, wq, sw, out=out, accumulate=True)
+    assert ((out.float() - (ref + r.float())).abs() / (rowmax + 1)).max().item() <= 1.2e-2
+
+
+def test_fp8_weights_are_quantised_once_per_optimizer_step(dev):
+    """ops.fp8_weight caches the e4m3 copies (row-scaled and transposed column-scaled) until the
+    optimizer runtime bumps the weight version or torch modifies the tensor in place"""
+    W = (torch.randn(256, 256) * 0.02).to(torch.bfloat16).to(dev)
+    calls = {"n": 0}
+    real_r, real_c = ops.quantize_fp8_rows, ops.quantize_fp8_cols_t
+
+    def cr(*a, **k):
+        calls["n"] += 1
+        return real_r(*a, **k)
+
+    def cc(*a, **k):
+        calls["n"] += 1
+        return real_c(*a, **k)
+    ops.quantize_fp8_rows, ops.quantize_fp8_cols_t = cr, cc
+    try:
+        ops.clear_fp8_cache()
+        a1 = ops.fp8_weight(W)
+        a2 = ops.fp8_weight(W)
+        t1 = ops.fp8_weight(W, transposed=True)
+        t2 = ops.fp8_weight(W[128:], transposed=True)           # another view: its own entry
+        assert calls["n"] == 3 and a1[0] is a2[0] and t1[0].shape == (256, 256) and t2[0].shape == (256, 128)
+        ops.bump_weight_version()                               # what BucketedStep.finish() / FusedAdamW do
+        ops.fp8_weight(W)
+        assert calls["n"] == 4
+        W.mul_(2)                                               # torch-side in-place edit
+        b = ops.fp8_weight(W)
+        assert calls["n"] == 5 and torch.allclose(b[1], a1[1] * 2)
+    finally:
+        ops.quantize_fp8_rows, ops.quantize_fp8_cols_t = real_r, real_c
+        ops.clear_fp8_cache()
+
+
+@pytest.mark.parametrize("mlp", [False, True])
+def test_model_with_fp8_against_the_oracle_and_the_format_yardstick(dev, mlp):
+    """MM_LLMs.set_fp8 (BASELINE cfg 5; mlp=True: gate|up / down too) judged against the ORACLE.  Three
+    runs of the same weights and inputs are compared with the fp32 oracle: the bf16 HIP engine
+    (e_bf16), the fp8 HIP engine (e_fp8), and the fp32 oracle with ONLY the fp8 path's operand
+    quantisation added (tests/fp8_ref.py: e_fmt = what the e4m3 format itself costs, no kernel
+    involved).  Bound: e_fp8 <= 1.5 * sqrt(e_fmt^2 + e_bf16^2) for logits and every gradient norm
+    -- derived from the format, not a percentage of range.  Forward and grad-input GEMMs of the
+    covered projections must really run on the fp8 path (counted)."""
     from golden_util import load_case
-    from oracle import configs
+    from oracle import configs, restate
+    from fp8_ref import fake_quant_oracle
     from test_model_gpu import build_model, to_dev
     from macaw_llm_amd import engine as E
     from macaw_llm_amd.modeling import MM_LLMs
@@ -79,15 +169,27 @@ def test_model_with_fp8_qkv_and_alignment(dev):
     cfg = configs.get(fx["config_name"])
     model = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=True).eval()
     inp = to_dev(fx["inputs"], dev)
+    names = [n for n, p in model.named_parameters() if p.requires_grad and n in fx["state"]]
 
     def run():
         model.zero_grad(set_to_none=True)
         out = model(inputs=inp)
         out.loss.backward()
-        gn = {n: p.grad.float().norm().item() for n, p in model.named_parameters() if p.grad is not None}
-        return out.logits.float().cpu(), out.loss.item(), gn
+        params = dict(model.named_parameters())
+        g = {n: params[n].grad.float().cpu().clone() for n in names if params[n].grad is not None}
+        return out.logits.float().cpu(), out.loss.item(), g
 
-    base_logits, base_loss, base_g = run()
+    def oracle(sites):
+        sd = {k: v.clone().requires_grad_(k in names) for k, v in fx["state"].items()}
+        with fake_quant_oracle(sites):
+            r = restate.mm_forward(sd, fx["inputs"], cfg)
+            r["loss"].backward()
+        return r["logits"].detach(), r["loss"].item(), {n: sd[n].grad for n in names if sd[n].grad is not None}
+
+    sites = ("qkv", "align", "mlp") if mlp else ("qkv", "align")
+    ref_logits, ref_loss, ref_g = oracle(())
+    fmt_logits, fmt_loss, fmt_g = oracle(sites)
+    b_logits, b_loss, b_g = run()
     calls = {"n": 0}
     real = E.ops.linear_fp8
 
@@ -95,20 +197,35 @@ def test_model_with_fp8_qkv_and_alignment(dev):
         calls["n"] += 1
         return real(*a, **k)
     try:
-        MM_LLMs.set_fp8(qkv=True, align=True)
+        MM_LLMs.set_fp8(qkv=True, align=True, mlp=mlp)
         E.ops.linear_fp8 = counting
         logits, loss, g = run()
     finally:
         E.ops.linear_fp8 = real
-        MM_LLMs.set_fp8(qkv=False, align=False)
-    assert calls["n"] == cfg["llama"]["num_hidden_layers"] + 3      # every layer's q|k|v + 3 modalities
+        MM_LLMs.set_fp8(qkv=False, align=False, mlp=False)
+    L, Dm, FFm = (cfg["llama"][k] for k in ("num_hidden_layers", "hidden_size", "intermediate_size"))
+    # forward + grad-input per covered projection: q|k|v (2 per layer), 3 modalities (2 each); MLP: each
+    # of gate|up fwd / down fwd / down dx / gate|up dx whose reduction length is a multiple of 128
+    n_mlp = sum(1 for red in (Dm, FFm, Dm, 2 * FFm) if red % 128 == 0) if mlp else 0
+    assert calls["n"] == 2 * L + 6 + n_mlp * L, calls["n"]
+
+    def nerr(a, ref):
+        return (a - ref).norm().item() / ref.norm().item()
+
+    e_fp8, e_fmt, e_b = nerr(logits, ref_logits), nerr(fmt_logits, ref_logits), nerr(b_logits, ref_logits)
+    print(f"fp8 (mlp={mlp}) logits rel L2 err vs fp32 oracle: HIP fp8 {e_fp8:.3e}, format yardstick {e_fmt:.3e}, "
+          f"HIP bf16 {e_b:.3e}; loss {loss:.5f} / {fmt_loss:.5f} / {b_loss:.5f} / fp32 {ref_loss:.5f}")
     assert torch.isfinite(logits).all()
-    span = base_logits.abs().max().item()
-    assert (logits - base_logits).abs().max().item() <= 8e-2 * span
-    assert abs(loss - base_loss) <= 5e-2 * abs(base_loss)
-    assert g.keys() == base_g.keys()
-    for n in g:
-        assert math.isfinite(g[n]) and abs(g[n] - base_g[n]) <= 0.25 * base_g[n] + 1e-4, (n, g[n], base_g[n])
+    assert e_fp8 <= 1.5 * math.hypot(e_fmt, e_b) + 1e-3, (e_fp8, e_fmt, e_b)
+    assert abs(loss - ref_loss) <= 1.5 * (abs(fmt_loss - ref_loss) + abs(b_loss - ref_loss)) + 2e-3
+    worst = 0.0
+    for n in names:
+        if n not in ref_g or ref_g[n].norm().item() == 0:
+            continue
+        ef, em, eb = nerr(g[n], ref_g[n]), nerr(fmt_g[n], ref_g[n]), nerr(b_g[n], ref_g[n])
+        worst = max(worst, ef / (1.5 * math.hypot(em, eb) + 2e-2))
+        assert ef <= 1.5 * math.hypot(em, eb) + 2e-2, (n, ef, em, eb)
+    print(f"fp8 (mlp={mlp}) gradients: worst ratio to the bound {worst:.2f}")
     # switched off again: bit-identical to the first run
     again, _, _ = run()
-    assert torch.equal(again, base_logits)
+    assert torch.equal(again, b_logits)

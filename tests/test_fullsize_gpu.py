@@ -438,7 +438,7 @@ def test_full_llama7b_checkpointing_bit_identical_and_gradients_vs_oracle(dev):
         assert e_hip <= 1.5 * e_eag + 1e-2, (k, e_hip, e_eag)
 
 
-def _full_model_vs_oracle(dev, cfg, inp, keys, tag, seed=11):
+def _full_model_vs_oracle(dev, cfg, inp, keys, tag, seed=11, fp8_sites=None):
     """shared body of the full-depth parity tests: bf16 HIP engine vs the fp32 oracle run with plain
     torch ops ON THE GPU (oracle.restate, pinned to the reference by tests/test_oracle.py), eager bf16
     through the same oracle code as the yardstick.  Returns the measured errors; asserts the
@@ -454,14 +454,35 @@ def _full_model_vs_oracle(dev, cfg, inp, keys, tag, seed=11):
     logits_hip, loss_hip = out.logits.detach().float().clone(), out.loss.item()
     del out
     model.zero_grad(set_to_none=True)
+    fp8 = None
+    if fp8_sites:
+        # the same model through the fp8 MFMA path (MM_LLMs.set_fp8), judged below against the fp32
+        # oracle with the bound derived from the format yardstick (tests/fp8_ref.py)
+        from macaw_llm_amd.modeling import MM_LLMs
+        try:
+            MM_LLMs.set_fp8(qkv="qkv" in fp8_sites, align="align" in fp8_sites, mlp="mlp" in fp8_sites)
+            out = model(inputs=inp)
+            out.loss.backward()
+            fp8 = dict(logits=out.logits.detach().float().clone(), loss=out.loss.item(),
+                       grads={k: dict(model.named_parameters())[k].grad.detach().float().clone() for k in keys})
+            del out
+        finally:
+            MM_LLMs.set_fp8(qkv=False, align=False, mlp=False)
+        model.zero_grad(set_to_none=True)
     res = {}
-    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+    import contextlib
+    from fp8_ref import fake_quant_oracle
+    passes = [("fp32", torch.float32, None), ("bf16", torch.bfloat16, None)]
+    if fp8_sites:
+        passes.append(("fmt", torch.float32, fp8_sites))
+    for name, dt, sites in passes:
         sd = {k: v.to(dt) for k, v in _gpu_oracle_state(model).items()}
         for k in keys:
             sd[k] = sd[k].clone().requires_grad_(True)
         fin = {k: (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}
-        r = restate.mm_forward(sd, fin, cfg)
-        r["loss"].backward()
+        with (fake_quant_oracle(sites) if sites else contextlib.nullcontext()):
+            r = restate.mm_forward(sd, fin, cfg)
+            r["loss"].backward()
         res[name] = dict(logits=r["logits"].detach().float(), loss=r["loss"].item(),
                          grads={k: sd[k].grad.float() for k in keys},
                          am=r["attention_mask"], lab=r["labels"], emb=r["inputs_embeds"].detach().float())
@@ -489,6 +510,21 @@ def _full_model_vs_oracle(dev, cfg, inp, keys, tag, seed=11):
         gerr[k] = (e_hip, e_eag)
         print(f"{tag} grad {k}: rel L2 err vs fp32 oracle: HIP bf16 {e_hip:.3e}, eager bf16 {e_eag:.3e}")
         assert e_hip <= 1.5 * e_eag + 1e-2, (k, e_hip, e_eag)
+    if fp8 is not None:
+        import math
+
+        def l2(a, b):
+            return (a - b).norm().item() / b.norm().item()
+        e8, ef, eb = l2(fp8["logits"], ref["logits"]), l2(res["fmt"]["logits"], ref["logits"]), l2(logits_hip, ref["logits"])
+        print(f"{tag} fp8 {fp8_sites}: logits rel L2 err vs fp32 oracle: HIP fp8 {e8:.3e}, e4m3 format yardstick "
+              f"{ef:.3e}, HIP bf16 {eb:.3e}; loss {fp8['loss']:.5f} (fmt {res['fmt']['loss']:.5f}, fp32 {ref['loss']:.5f})")
+        assert e8 <= 1.5 * math.hypot(ef, eb) + 1e-3, (e8, ef, eb)
+        assert abs(fp8["loss"] - ref["loss"]) <= 2e-2 * max(1.0, abs(ref["loss"]))
+        for k in keys:
+            want = ref["grads"][k]
+            g8, gf, gb = l2(fp8["grads"][k], want), l2(res["fmt"]["grads"][k], want), l2(g_hip[k], want)
+            print(f"{tag} fp8 grad {k}: HIP fp8 {g8:.3e}, format yardstick {gf:.3e}, HIP bf16 {gb:.3e}")
+            assert g8 <= 1.5 * math.hypot(gf, gb) + 1e-2, (k, g8, gf, gb)
     del model, res
     torch.cuda.empty_cache()
     return hip, eag, gerr
@@ -516,14 +552,17 @@ def test_full_llama13b_against_fp32_oracle_on_gpu(dev):
     """BASELINE cfg 5 backbone at FULL depth: the 40-layer LLaMA-13B (D = 5120, FF = 13824, 40 heads) +
     CLIP-L/14 + Whisper-base, image + 30 s audio + 128 tokens, B = 2 (53 GB of fp32 oracle weights
     beside the 27 GB bf16 model): logits, loss and six gradients vs the fp32 oracle, eager bf16 as
-    yardstick -- the same bar as the 7B test."""
+    yardstick -- the same bar as the 7B test -- and once more with BASELINE cfg 5's precision
+    (MM_LLMs.set_fp8: e4m3 forward + grad-input of q|k|v and of the alignment K/V projection) against
+    the SAME fp32 oracle, bounded by what the e4m3 format itself costs (the fp32 oracle with only the
+    operand quantisation added, tests/fp8_ref.py) combined with the bf16 engine's own error."""
     from macaw_llm_amd.factory import baseline_config, synthetic_inputs
     cfg = baseline_config("real_13b")
     inp = synthetic_inputs(cfg, 2, 128, modalities=("images", "audios"), seed=5, device=dev)
     keys = ["llm.lm_head.weight", "llm.model.norm.weight", "llm.model.layers.39.mlp.down_proj.weight",
             "llm.model.layers.39.self_attn.q_proj.weight", "llm.model.layers.0.mlp.gate_proj.weight",
             "llm.model.layers.0.self_attn.v_proj.weight"]
-    _full_model_vs_oracle(dev, cfg, inp, keys, "13B (cfg 5 backbone)")
+    _full_model_vs_oracle(dev, cfg, inp, keys, "13B (cfg 5 backbone)", fp8_sites=("qkv", "align"))
 
 
 def test_cfg4_sequence_2048_video_audio_text_full_model(dev):

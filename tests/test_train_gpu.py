@@ -82,11 +82,14 @@ def _worker_two_ranks_one_gpu(rank, world, port, q, shard):
         from macaw_llm_amd.optim import FusedAdamW
         from legacy_steps import OverlappedStep
         dev = torch.device("cuda:0")
+        from conftest import poison_allocator
+        poison_allocator(256, 256)
         fx = load_case("micro_all")
         cfg = configs.get(fx["config_name"])
         model = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=True).eval()
         params = [p for p in model.parameters() if p.requires_grad]
         opt = FusedAdamW(params, lr=1e-3, weight_decay=0.01)
+        poison_allocator(256, 256)
         rt = OverlappedStep(params, opt, small_threshold=4096, shard_optimizer=shard)
         inp = to_dev(fx["inputs"], dev)
         # every rank sees its own half of the batch (2 samples -> 1 each)
@@ -292,11 +295,14 @@ def _worker_bucketed_two_ranks(rank, world, port, q):
         from macaw_llm_amd.optim import FusedAdamW
         from macaw_llm_amd.bucketed import BucketedStep
         dev = torch.device("cuda:0")
+        from conftest import poison_allocator
+        poison_allocator(256, 256)
         fx = load_case("micro_all")
         cfg = configs.get(fx["config_name"])
         model = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=True).eval()
         params = [p for p in model.parameters() if p.requires_grad]
         opt = FusedAdamW(params, lr=1e-3, weight_decay=0.01)
+        poison_allocator(256, 256)
         rt = BucketedStep(params, opt, bucket_bytes=64 << 10)
         inp = to_dev(fx["inputs"], dev)
         mine = {k: (v[rank:rank + 1] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 2 else v)
@@ -388,14 +394,15 @@ def test_graphed_step_is_bit_identical_to_the_eager_step(dev):
         assert torch.equal(pe[n], pg[n]), n
 
 
-@pytest.mark.parametrize("inject", [None, "1"])
+@pytest.mark.parametrize("inject", [None, "all"])
 def test_bench_py_runs_its_n_gt_1_branch_with_two_ranks_on_this_gpu(dev, inject):
     """bench.py's N > 1 branch (process-group setup, BucketedStep ZeRO-1 with the frozen bucket order,
     cross-rank agreement on a failed setup step, max-over-ranks timing, describe()) had never executed
     before the driver's 8-GPU run (round-2 verdict).  Here it runs as two torchrun ranks sharing this
     GPU over gloo (MACAW_SHARE_GPU / MACAW_DIST_BACKEND; 2-layer model, marked invalid as a
-    benchmark).  inject="1": rank 1 fails its setup step -- BOTH ranks must fall back together to
-    all-reduce + replicated AdamW and say so in config.parallelism."""
+    benchmark).  inject="all": the ZeRO-1 setup step fails on every rank (the symmetric failure a
+    missing collective or an OOM produces) -- the ranks must agree, fall back TOGETHER to all-reduce +
+    replicated AdamW and say so in config.parallelism."""
     import json
     import os
     import subprocess
@@ -407,7 +414,7 @@ def test_bench_py_runs_its_n_gt_1_branch_with_two_ranks_on_this_gpu(dev, inject)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--layers", "2", "--batch-per-gpu", "2", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]           # rank 0 prints ONE line
