@@ -153,6 +153,8 @@ class BucketedStep:
         self.overlap = overlap
         self.direct_grads = direct_grads
         self.dev_hyper = False         # True while train.GraphedStep captures: AdamW scalars from device memory
+        self.grad_scale = 1.0          # multiplied into every gradient inside AdamW (set to 1 / loss_scale for
+                                       # fp16 training with a scaled loss; set it before the backward)
         self.grad_norm = None          # device scalar (fp32) of the last clipped step
         self._micro = 0
         self._order = None             # frozen launch order (bucket indices); None until the discovery step ran
@@ -325,7 +327,8 @@ class BucketedStep:
             self._cursor += 1
 
     def _acc_scale(self) -> float:
-        return 1.0 / self.accumulate_steps if (self.average_accumulated and self.accumulate_steps > 1) else 1.0
+        acc = 1.0 / self.accumulate_steps if (self.average_accumulated and self.accumulate_steps > 1) else 1.0
+        return acc * float(self.grad_scale)
 
     def _launch(self, b: _Bucket):
         b.launched = True

@@ -43,7 +43,8 @@ def _digest(paths) -> str:
 
 def build(force: bool = False, verbose: bool = True) -> Path:
     srcs = [CSRC / s for s in SOURCES]
-    deps = srcs + [CSRC / "common.h", CSRC / "gemm_common.h", PKG.parent / "include" / "macaw_hip.h"]
+    deps = srcs + [CSRC / "common.h", CSRC / "gemm_common.h", PKG.parent / "include" / "macaw_hip.h",
+                   *sorted(CSRC.glob("*_impl.inc"))]
     stamp = OBJ / "stamp.txt"
     dig = _digest(deps)
     if not force and LIB.exists() and stamp.exists() and stamp.read_text() == dig:

@@ -22,6 +22,10 @@ typedef __bf16 bf16;
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -77,6 +81,15 @@ template <> MK_DEV float rnd<bf16>(float v) {
   return __uint_as_float(u & 0xffff0000u);
 }
 
+// fp16 (the reference's `--fp16 True` / `.to(torch.float16)`, train.sh:36, llm_trainer.py:411-412):
+// RNE through v_cvt_f16_f32 / v_cvt_f32_f16; written in asm so that fast-math cannot fold the
+// round trip away (same reason as the bit trick of the bf16 form).
+template <> MK_DEV float rnd<_Float16>(float v) {
+  float r;
+  asm volatile("v_cvt_f16_f32 %0, %1\n\tv_cvt_f32_f16 %0, %0" : "=v"(r) : "v"(v));
+  return r;
+}
+
 // Vector-of-VEC access: VEC elements of T moved as one 16-byte (bf16x8) or
 // 16-byte (float4) transaction.  VecIO<T>::N elements per 16 B.
 template <typename T> struct VecIO;
@@ -102,6 +115,46 @@ template <> struct VecIO<bf16> {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (bf16)o[i];
     *reinterpret_cast<bf16x8*>(p) = v;
+  }
+};
+
+template <> struct VecIO<_Float16> {
+  static constexpr int N = 8;
+  MK_DEV static void load(const _Float16* p, float (&o)[8]) {
+    f16x8 v = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
+  MK_DEV static void store(_Float16* p, const float (&o)[8]) {
+    f16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (_Float16)o[i];
+    *reinterpret_cast<f16x8*>(p) = v;
+  }
+};
+
+// ---- 16-bit MFMA element traits: the kernels of gemm*.hip / attention.hip / decode.hip are written
+// once over an element type e16 (bf16 or f16, `*_impl.inc` included twice); everything that depends on
+// the element type beyond plain conversions goes through here.  Same instruction rates for both.
+template <typename T> struct E16;
+template <> struct E16<bf16> {
+  typedef bf16x8 x8; typedef bf16x4 x4;
+  static constexpr int dtype = MK_BF16;
+  MK_DEV static f32x16 mma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  MK_DEV static f32x4 mma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  MK_DEV static x4 tr_read(const char* lds) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds));
+  }
+};
+template <> struct E16<_Float16> {
+  typedef f16x8 x8; typedef f16x4 x4;
+  static constexpr int dtype = MK_F16;
+  MK_DEV static f32x16 mma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  MK_DEV static f32x4 mma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  MK_DEV static x4 tr_read(const char* lds) {
+    // (ds_read_b64_tr_b16 moves 16-bit lanes, the element format is irrelevant to it)
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                         (__attribute__((address_space(3))) bf16x4*)(lds)));
   }
 };
 

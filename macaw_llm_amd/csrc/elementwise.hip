@@ -509,6 +509,7 @@ __global__ __launch_bounds__(256) void fp8_zero_n_kernel(float* p, int n) {
 #define MK_DISPATCH_T(dtype, CALL)                     \
   do {                                                 \
     if ((dtype) == MK_BF16) { using T = bf16; CALL; }  \
+    else if ((dtype) == MK_F16) { using T = _Float16; CALL; } \
     else if ((dtype) == MK_F32) { using T = float; CALL; } \
     else return MK_ERR_UNSUPPORTED;                    \
   } while (0)

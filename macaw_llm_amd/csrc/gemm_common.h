@@ -68,9 +68,10 @@ MK_DEV void tile_from_index(int wg, int tiles_m, int tiles_n, int& tm, int& tn, 
 // fp32 in its private 8 KiB (float4 index XOR row: conflict-free both ways), reads them back
 // row-major -- 16 lanes per 64-column row -- and every load / store is a full 128-byte line per
 // row; the residual rows of a pass group are all requested before the first is used.
-template <int FM, int FN>
-MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* C, const bf16* Rp,
+template <typename ET, int FM, int FN>
+MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, ET* C, const ET* Rp,
                           int m0, int n0, int wm0, int wn0, char* smem) {
+  typedef typename E16<ET>::x4 e16x4;
   constexpr int W4 = FN * 8;        // float4 per staged row
   constexpr int RPI = 64 / W4;      // rows per pass
   constexpr int NPASS = 32 / RPI;   // passes per 32-row fragment
@@ -96,7 +97,7 @@ MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* 
   }
   float bv[4] = {0.f, 0.f, 0.f, 0.f};
   if (g.bias_mode == 1) {
-    const bf16* bp = reinterpret_cast<const bf16*>(g.bias);
+    const ET* bp = reinterpret_cast<const ET*>(g.bias);
 #pragma unroll
     for (int e = 0; e < 4; ++e) bv[e] = (float)bp[min(ncol + e, g.N - 1)];
   }
@@ -114,12 +115,12 @@ MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* 
     const int mbase = m0 + wm0 + i * 32 + rsub;
     if (fast) {
       // residual / accumulate rows of ALL passes requested up front (clamped row, discarded later)
-      bf16x4 rv[NPASS], cv[NPASS];
+      e16x4 rv[NPASS], cv[NPASS];
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
         const long mc = min(mbase + p * RPI, g.M - 1);
-        if (Rp) rv[p] = *reinterpret_cast<const bf16x4*>(Rp + mc * g.ldr + ncol);
-        if (g.accumulate) cv[p] = *reinterpret_cast<const bf16x4*>(C + mc * g.ldc + ncol);
+        if (Rp) rv[p] = *reinterpret_cast<const e16x4*>(Rp + mc * g.ldr + ncol);
+        if (g.accumulate) cv[p] = *reinterpret_cast<const e16x4*>(C + mc * g.ldc + ncol);
       }
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
@@ -134,7 +135,7 @@ MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* 
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bv[e];
         } else if (g.bias_mode == 2) {
-          const float bm = (float)reinterpret_cast<const bf16*>(g.bias)[min(m, g.M - 1)];
+          const float bm = (float)reinterpret_cast<const ET*>(g.bias)[min(m, g.M - 1)];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bm;
         }
@@ -151,10 +152,10 @@ MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* 
           for (int e = 0; e < 4; ++e) v[e] += (float)cv[p][e];
         }
         if (m < g.M) {
-          bf16x4 o;
+          e16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-          *reinterpret_cast<bf16x4*>(C + (long)m * g.ldc + ncol) = o;
+          for (int e = 0; e < 4; ++e) o[e] = (ET)v[e];
+          *reinterpret_cast<e16x4*>(C + (long)m * g.ldc + ncol) = o;
         }
       }
     } else {
@@ -166,7 +167,7 @@ MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* 
         const float tv[4] = {t.x, t.y, t.z, t.w};
         if (m >= g.M) continue;
         float bm = 0.f;
-        if (g.bias_mode == 2) bm = (float)reinterpret_cast<const bf16*>(g.bias)[m];
+        if (g.bias_mode == 2) bm = (float)reinterpret_cast<const ET*>(g.bias)[m];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int n = ncol + e;
@@ -176,9 +177,9 @@ MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, bf16* 
           else if (g.bias_mode == 2) x += bm;
           if (g.act) x = apply_act(x, g.act);
           if (Rp) x += (float)Rp[(long)m * g.ldr + n];
-          bf16* cp = C + (long)m * g.ldc + n;
+          ET* cp = C + (long)m * g.ldc + n;
           if (g.accumulate) x += (float)*cp;
-          *cp = (bf16)x;
+          *cp = (ET)x;
         }
       }
     }

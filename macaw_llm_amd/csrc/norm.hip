@@ -346,6 +346,10 @@ extern "C" int mk_rmsnorm_fwd(const void* x, const void* res, const void* w, voi
     if (cols % 8) return MK_ERR_UNSUPPORTED;
     MK_LAUNCH((rmsnorm_fwd_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x,
                        (const bf16*)res, (const bf16*)w, (bf16*)h_out, (bf16*)y, rstd, cols, eps);
+  } else if (dtype == MK_F16) {
+    if (cols % 8) return MK_ERR_UNSUPPORTED;
+    MK_LAUNCH((rmsnorm_fwd_kernel<_Float16>), grid, block, 0, MK_ST, (const _Float16*)x,
+                       (const _Float16*)res, (const _Float16*)w, (_Float16*)h_out, (_Float16*)y, rstd, cols, eps);
   } else if (dtype == MK_F32) {
     if (cols % 4) return MK_ERR_UNSUPPORTED;
     MK_LAUNCH((rmsnorm_fwd_kernel<float>), grid, block, 0, MK_ST, (const float*)x,
@@ -360,7 +364,8 @@ extern "C" int mk_rmsnorm_bwd(const void* dy, const void* h, const void* w, cons
                               int32_t rows, int32_t cols, int32_t dtype, void* stream) {
   if (!dy || !h || !w || !rstd || !dx || !dw_partial || nblk <= 0 || rows <= 0) return MK_ERR_BAD_ARG;
   if (dtype == MK_BF16)
-    return rmsnorm_bwd_launch<bf16>(dy, h, w, rstd, dres_in, dx, dw_partial, nblk, rows, cols, MK_ST);
+    return rmsnorm_bwd_launch<bf16>(dy, h, w, rstd, dres_in, dx, dw_partial, nblk, rows, cols, MK_ST); else if (dtype == MK_F16)
+    return rmsnorm_bwd_launch<_Float16>(dy, h, w, rstd, dres_in, dx, dw_partial, nblk, rows, cols, MK_ST);
   if (dtype == MK_F32)
     return rmsnorm_bwd_launch<float>(dy, h, w, rstd, dres_in, dx, dw_partial, nblk, rows, cols, MK_ST);
   return MK_ERR_UNSUPPORTED;
@@ -385,7 +390,9 @@ extern "C" int mk_layernorm_fwd(const void* x, const void* w, const void* b, voi
   }
   if (dtype == MK_BF16)
     MK_LAUNCH((layernorm_fwd_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x,
-                       (const bf16*)w, (const bf16*)b, (bf16*)y, mean, rstd, cols, eps);
+                       (const bf16*)w, (const bf16*)b, (bf16*)y, mean, rstd, cols, eps); else if (dtype == MK_F16)
+    MK_LAUNCH((layernorm_fwd_kernel<_Float16>), grid, block, 0, MK_ST, (const _Float16*)x,
+                       (const _Float16*)w, (const _Float16*)b, (_Float16*)y, mean, rstd, cols, eps);
   else if (dtype == MK_F32)
     MK_LAUNCH((layernorm_fwd_kernel<float>), grid, block, 0, MK_ST, (const float*)x,
                        (const float*)w, (const float*)b, (float*)y, mean, rstd, cols, eps);
@@ -401,6 +408,8 @@ extern "C" int mk_layernorm_bwd(const void* dy, const void* x, const void* w, co
     return MK_ERR_BAD_ARG;
   if (dtype == MK_BF16)
     return layernorm_bwd_launch<bf16>(dy, x, w, mean, rstd, dres_in, dx, dw_partial, db_partial,
+                                      nblk, rows, cols, MK_ST); else if (dtype == MK_F16)
+    return layernorm_bwd_launch<_Float16>(dy, x, w, mean, rstd, dres_in, dx, dw_partial, db_partial,
                                       nblk, rows, cols, MK_ST);
   if (dtype == MK_F32)
     return layernorm_bwd_launch<float>(dy, x, w, mean, rstd, dres_in, dx, dw_partial, db_partial,
@@ -414,6 +423,8 @@ extern "C" int mk_colsum_partials(const float* partial, void* out, int32_t nblk,
   dim3 grid(mk_cdiv(cols, 32)), block(256);
   if (dtype == MK_BF16)
     MK_LAUNCH((colsum_partials_kernel<bf16>), grid, block, 0, MK_ST, partial, (bf16*)out,
+                       nblk, cols, accumulate); else if (dtype == MK_F16)
+    MK_LAUNCH((colsum_partials_kernel<_Float16>), grid, block, 0, MK_ST, partial, (_Float16*)out,
                        nblk, cols, accumulate);
   else if (dtype == MK_F32)
     MK_LAUNCH((colsum_partials_kernel<float>), grid, block, 0, MK_ST, partial,
@@ -429,6 +440,8 @@ extern "C" int mk_colsum(const void* x, int64_t ld, void* out, float* ws, int32_
   dim3 grid(mk_cdiv(cols, 256), nblk), block(256);
   if (dtype == MK_BF16)
     MK_LAUNCH((colsum_rows_kernel<bf16>), grid, block, 0, MK_ST, (const bf16*)x, (long)ld,
+                       ws, rows, cols); else if (dtype == MK_F16)
+    MK_LAUNCH((colsum_rows_kernel<_Float16>), grid, block, 0, MK_ST, (const _Float16*)x, (long)ld,
                        ws, rows, cols);
   else if (dtype == MK_F32)
     MK_LAUNCH((colsum_rows_kernel<float>), grid, block, 0, MK_ST, (const float*)x,

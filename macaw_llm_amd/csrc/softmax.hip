@@ -13,6 +13,7 @@ namespace {
 template <typename T> MK_DEV float finfo_min();
 template <> MK_DEV float finfo_min<float>() { return -3.4028234663852886e38f; }
 template <> MK_DEV float finfo_min<bf16>() { return -3.3895313892515355e38f; }
+template <> MK_DEV float finfo_min<_Float16>() { return -65504.f; }   // torch.finfo(torch.float16).min
 
 MK_DEV uint32_t keep_thr(float p) {
   const double k = (1.0 - (double)p) * 4294967296.0;
@@ -329,12 +330,23 @@ MK_DEV void adam_load4(const bf16* p, float (&o)[4]) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) o[k] = (float)v[k];
 }
+MK_DEV void adam_load4(const _Float16* p, float (&o)[4]) {
+  const f16x4 v = *reinterpret_cast<const f16x4*>(p);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (float)v[k];
+}
 MK_DEV void adam_load4(const float* p, float (&o)[4]) { VecIO<float>::load(p, o); }
 MK_DEV void adam_store4(bf16* p, const float (&o)[4]) {
   bf16x4 v;
 #pragma unroll
   for (int k = 0; k < 4; ++k) v[k] = (bf16)o[k];
   *reinterpret_cast<bf16x4*>(p) = v;
+}
+MK_DEV void adam_store4(_Float16* p, const float (&o)[4]) {
+  f16x4 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = (_Float16)o[k];
+  *reinterpret_cast<f16x4*>(p) = v;
 }
 MK_DEV void adam_store4(float* p, const float (&o)[4]) { VecIO<float>::store(p, o); }
 
@@ -550,6 +562,8 @@ extern "C" int mk_softmax_fwd(const void* scores, void* probs, void* probs_drop,
   if ((al & 15) || ld % 8) return MK_ERR_UNSUPPORTED;  // rows must be 16-byte aligned, pitch % 8
   if (dtype == MK_BF16)
     return softmax_fwd_t<bf16>(scores, probs, probs_drop, kmask, nz, heads, Lq, Lk, ld, causal,
+                               dropout_p, seed, MK_ST); else if (dtype == MK_F16)
+    return softmax_fwd_t<_Float16>(scores, probs, probs_drop, kmask, nz, heads, Lq, Lk, ld, causal,
                                dropout_p, seed, MK_ST);
   if (dtype == MK_F32)
     return softmax_fwd_t<float>(scores, probs, probs_drop, kmask, nz, heads, Lq, Lk, ld, causal,
@@ -564,7 +578,8 @@ extern "C" int mk_softmax_bwd(const void* probs, void* dprobs, int32_t nz, int32
   const uintptr_t al = reinterpret_cast<uintptr_t>(probs) | reinterpret_cast<uintptr_t>(dprobs);
   if ((al & 15) || ld % 8) return MK_ERR_UNSUPPORTED;
   if (dtype == MK_BF16)
-    return softmax_bwd_t<bf16>(probs, dprobs, nz, Lq, Lk, ld, scale, dropout_p, seed, MK_ST);
+    return softmax_bwd_t<bf16>(probs, dprobs, nz, Lq, Lk, ld, scale, dropout_p, seed, MK_ST); else if (dtype == MK_F16)
+    return softmax_bwd_t<_Float16>(probs, dprobs, nz, Lq, Lk, ld, scale, dropout_p, seed, MK_ST);
   if (dtype == MK_F32)
     return softmax_bwd_t<float>(probs, dprobs, nz, Lq, Lk, ld, scale, dropout_p, seed, MK_ST);
   return MK_ERR_UNSUPPORTED;
@@ -578,6 +593,8 @@ extern "C" int mk_cross_entropy(const void* logits, const int64_t* labels, float
     return MK_ERR_BAD_ARG;
   if (dtype == MK_BF16)
     MK_LAUNCH((ce_fwd_kernel<bf16>), dim3(rows), dim3(256), 0, MK_ST, (const bf16*)logits,
+                       labels, row_loss, row_lse, V, (long)ld); else if (dtype == MK_F16)
+    MK_LAUNCH((ce_fwd_kernel<_Float16>), dim3(rows), dim3(256), 0, MK_ST, (const _Float16*)logits,
                        labels, row_loss, row_lse, V, (long)ld);
   else if (dtype == MK_F32)
     MK_LAUNCH((ce_fwd_kernel<float>), dim3(rows), dim3(256), 0, MK_ST,
@@ -598,6 +615,9 @@ extern "C" int mk_cross_entropy_bwd(const void* logits, void* dlogits, const int
   if (dtype == MK_BF16)
     MK_LAUNCH((ce_bwd_kernel<bf16>), dim3(rows), dim3(256), 0, MK_ST, (const bf16*)logits,
                        (bf16*)dlogits, labels, row_lse, loss_sum_cnt, grad_scale, grad_scale_dev, V,
+                       (long)ld); else if (dtype == MK_F16)
+    MK_LAUNCH((ce_bwd_kernel<_Float16>), dim3(rows), dim3(256), 0, MK_ST, (const _Float16*)logits,
+                       (_Float16*)dlogits, labels, row_lse, loss_sum_cnt, grad_scale, grad_scale_dev, V,
                        (long)ld);
   else if (dtype == MK_F32)
     MK_LAUNCH((ce_bwd_kernel<float>), dim3(rows), dim3(256), 0, MK_ST,
@@ -626,6 +646,9 @@ extern "C" int mk_adamw(void* param, float* master, float* m, float* v, const vo
   if (dtype == MK_BF16)
     MK_LAUNCH((adamw_kernel<bf16>), grid, block, 0, MK_ST, (bf16*)param, master, m, v,
                        (const bf16*)grad, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                       grad_scale); else if (dtype == MK_F16)
+    MK_LAUNCH((adamw_kernel<_Float16>), grid, block, 0, MK_ST, (_Float16*)param, master, m, v,
+                       (const _Float16*)grad, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
                        grad_scale);
   else if (dtype == MK_F32)
     MK_LAUNCH((adamw_kernel<float>), grid, block, 0, MK_ST, (float*)param, master, m, v,
@@ -640,6 +663,8 @@ extern "C" int mk_argmax_rows(const void* x, int64_t ld, int32_t rows, int32_t c
   if (!x || !out || rows <= 0 || cols <= 0 || ld < cols) return MK_ERR_BAD_ARG;
   if (dtype == MK_BF16)
     MK_LAUNCH((argmax_rows_kernel<bf16>), dim3(rows), dim3(256), 0, MK_ST, (const bf16*)x, (long)ld,
+              cols, out); else if (dtype == MK_F16)
+    MK_LAUNCH((argmax_rows_kernel<_Float16>), dim3(rows), dim3(256), 0, MK_ST, (const _Float16*)x, (long)ld,
               cols, out);
   else if (dtype == MK_F32)
     MK_LAUNCH((argmax_rows_kernel<float>), dim3(rows), dim3(256), 0, MK_ST, (const float*)x,
@@ -661,6 +686,8 @@ extern "C" int mk_adamw_multi(const void* items, const int64_t* chunk_start, int
   const long* cs = reinterpret_cast<const long*>(chunk_start);
   if (dtype == MK_BF16)
     MK_LAUNCH((adamw_multi_kernel<bf16>), grid, block, 0, MK_ST, it, cs, n_items, lr, beta1, beta2, eps,
+              weight_decay, bc1, bc2, grad_scale, (const float*)nullptr); else if (dtype == MK_F16)
+    MK_LAUNCH((adamw_multi_kernel<_Float16>), grid, block, 0, MK_ST, it, cs, n_items, lr, beta1, beta2, eps,
               weight_decay, bc1, bc2, grad_scale, (const float*)nullptr);
   else if (dtype == MK_F32)
     MK_LAUNCH((adamw_multi_kernel<float>), grid, block, 0, MK_ST, it, cs, n_items, lr, beta1, beta2, eps,
@@ -689,6 +716,8 @@ extern "C" int mk_adamw_multi_dev(const void* items, const int64_t* chunk_start,
   const long* cs = reinterpret_cast<const long*>(chunk_start);
   if (dtype == MK_BF16)
     MK_LAUNCH((adamw_multi_kernel<bf16>), grid, block, 0, MK_ST, it, cs, n_items, 0.f, beta1, beta2, eps,
+              weight_decay, 1.f, 1.f, 1.f, hyper_dev); else if (dtype == MK_F16)
+    MK_LAUNCH((adamw_multi_kernel<_Float16>), grid, block, 0, MK_ST, it, cs, n_items, 0.f, beta1, beta2, eps,
               weight_decay, 1.f, 1.f, 1.f, hyper_dev);
   else if (dtype == MK_F32)
     MK_LAUNCH((adamw_multi_kernel<float>), grid, block, 0, MK_ST, it, cs, n_items, 0.f, beta1, beta2, eps,

