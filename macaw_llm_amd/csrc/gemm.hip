@@ -462,6 +462,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     g.ws = nullptr;
     g.counters = nullptr;
     g.ablate = 0;
+    g.tail8 = 0;
     // resident workgroups per CU of the chosen kernel
     const int slots = n_cus * (t256 ? 1 : (cfg == 7 ? 4 : 2));
     static const bool no_streamk = getenv("MK_GEMM_NO_STREAMK") != nullptr;
@@ -469,7 +470,15 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
       // v7: the last partial round of 256x256 tiles is computed as four 128x128 sub-tiles each
       // (one workgroup per sub-tile, full K, no partial sums) when that takes fewer rounds
       const int T = g.tiles_m * g.tiles_n, R = T % n_cus;
-      if (R > 0 && 4 * R <= 2 * n_cus) {
+      static const bool no_tail8 = getenv("MK_GEMM_NO_TAIL8") != nullptr;
+      if (R > 0 && 8 * R <= n_cus && !d->a_red_major && !no_tail8) {
+        // few tail tiles (288 = 256 + 32, 774 = 768 + 6, 1548 = 1536 + 12): 64 x 128 eighths so that
+        // the tail runs as ONE short round on up to all CUs (a 32-tile tail as quarters keeps half
+        // of the chip idle for a longer round)
+        g.dp_tiles = T - R;
+        g.tail8 = 1;
+        grid.x = g.dp_tiles + 8 * R;
+      } else if (R > 0 && 4 * R <= 2 * n_cus) {
         g.dp_tiles = T - R;
         grid.x = g.dp_tiles + 4 * R;
       }

@@ -24,6 +24,7 @@ struct GemmArgs {
   // stream-K tail (v2 kernel only): blocks [0, dp_tiles) own whole tiles; the remaining
   // tiles are cut into `split` K-pieces of `kt_per_piece` K-tiles, one block each.
   int dp_tiles, split, kt_per_piece;
+  int tail8;       // v7: the spatial tail is cut into 64 x 128 eighths (K-major A, <= 32 tail tiles) instead of quarters
   int lin_batch;   // 1: batch index is folded into the linear tile index (grid.z == 1)
   int ablate;      // debug only (MK_GEMM_ABLATE): 1 = skip global->LDS, 2 = skip barrier wait
   const void* pro_w; float pro_eps;   // skinny kernel prologue (mk_decode_linear): RMSNorm weight / eps

@@ -26,6 +26,16 @@ for step in "$@"; do
       timeout 400 python bench.py --config 5 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_cfg5_fp8.json 2> $out/bench_cfg5_fp8.err
       timeout 400 python bench.py --config 5 --steps 4 --warmup 2 --no-cpu-baseline --no-fp8 > $out/bench_cfg5_bf16.json 2> $out/bench_cfg5_bf16.err
       timeout 400 python bench.py --config 5 --steps 4 --warmup 2 --no-cpu-baseline --fp8-mlp > $out/bench_cfg5_fp8mlp.json 2> $out/bench_cfg5_fp8mlp.err ;;
+    splitk)
+      timeout 300 python scripts/probe/splitk_stress.py 3000 2 0 > $out/splitk_idle.txt 2>&1
+      timeout 400 python scripts/probe/splitk_stress.py 3000 3 1 > $out/splitk_burner.txt 2>&1 ;;
+    tailab)
+      for i in 1 2; do
+        MK_GEMM_NO_TAIL8=1 scripts/probe/_probe_gemm_bench scripts/gemm_shapes_tail.txt > $out/tail_quarters_$i.csv 2> $out/tail_q.err
+        scripts/probe/_probe_gemm_bench scripts/gemm_shapes_tail.txt > $out/tail_eighths_$i.csv 2> $out/tail_e.err
+      done ;;
+    cfg5one)
+      timeout 400 python bench.py --config 5 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_cfg5_fp8.json 2> $out/bench_cfg5_fp8.err ;;
     cfg4)
       timeout 400 python bench.py --config 4 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_cfg4.json 2> $out/bench_cfg4.err ;;
     bench)

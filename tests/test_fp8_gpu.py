@@ -117,7 +117,7 @@ def test_fp8_gemm_with_per_row_scales_on_both_tile_kernels(dev, M, N, K):
     r = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev)
     out = r.clone()
     ops.linear_fp8(xq, sx, wq, sw, out=out, accumulate=True)
-    assert ((out.float() - (ref + r.float())).abs() / (rowmax + 1)).max().item() <= 1.2e-2
+    assert ((out.float() - (ref + r.float())).abs() / (rowmax + 1)).max().item() <= 2e-2    # two bf16 roundings
 
 
 def test_fp8_weights_are_quantised_once_per_optimizer_step(dev):
