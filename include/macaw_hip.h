@@ -13,7 +13,9 @@
  *     unless noted; nothing is allocated or retained; asynchronous on `stream`
  *     (a hipStream_t passed as void*).
  *   - return value: 0 on success, <0 on error (MK_ERR_*). Never aborts.
- *   - dtype codes: 0 = f32, 1 = bf16, 2 = f16 (f16 only for mk_cast input).
+ *   - dtype codes: 0 = f32, 1 = bf16, 2 = f16.  Every kernel exists for all three (the reference's
+ *     scripts run fp16: train.sh:36, llm_trainer.py:411-412) except where a comment says otherwise
+ *     (fp8 quantisation and the host-input pipeline take bf16 / f32); accumulation is always f32.
  *   - matrices are row-major with an explicit leading dimension (elements).
  */
 #ifndef MACAW_HIP_H
