@@ -7,8 +7,8 @@
 #   gpurun_out/<R>_gemm_pmc/                          PMC passes of the v7 / v2 kernels on one LLaMA shape
 #   gpurun_out/<R>_write_calibration.txt              WRITE_SIZE of a known 1 GiB memset (counter calibration)
 # usage: scripts/profile_round.sh r02 [what...]   what in: bench prof traffic gemmpmc rccl   (default: all)
-R=${1:-r02}; shift
-WHAT=${*:-bench prof traffic gemmpmc rccl}
+R=${1:-r03}; shift
+WHAT=${*:-bench prof traffic gemmpmc rccl parity}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 has() { [[ " $WHAT " == *" $1 "* ]]; }
@@ -18,6 +18,9 @@ if has bench; then
   for c in 2 4 5; do
     timeout 500 python bench.py --config $c --steps 5 --warmup 2 > $OUT/${R}_bench_cfg$c.json 2> $OUT/${R}_bench_cfg$c.err
   done
+  # cfg 5: the bf16 yardstick of its fp8 speed-up, and the fp8 path extended to the MLP GEMMs
+  timeout 500 python bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline --no-fp8 > $OUT/${R}_bench_cfg5_bf16.json 2> $OUT/${R}_bench_cfg5_bf16.err
+  timeout 500 python bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline --fp8-mlp > $OUT/${R}_bench_cfg5_fp8mlp.json 2> $OUT/${R}_bench_cfg5_fp8mlp.err
 fi
 if has prof; then
   for c in 3 2 4 5; do
@@ -30,13 +33,18 @@ if has prof; then
 fi
 if has traffic; then
   cd /tmp
-  for ctr in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/pmc_$ctr
-    timeout 600 rocprofv3 --pmc $ctr -d /tmp/pmc_$ctr -o p --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${R}_pmc_$ctr.err
+  # one pair of --pmc passes per configuration (bench.py reports `roofline.traffic` only from a PMC
+  # profile of the SAME configuration): cfg 3 -> _step_traffic_pmc.csv, cfg N -> _step_traffic_pmc_cfgN.csv
+  for c in 3 2 4 5; do
+    for ctr in FETCH_SIZE WRITE_SIZE; do
+      rm -rf /tmp/pmc_$ctr
+      timeout 600 rocprofv3 --pmc $ctr -d /tmp/pmc_$ctr -o p --output-format csv -- python $ROOT/bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${R}_pmc_${ctr}_cfg$c.err
+    done
+    fr=$(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
+    fw=$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
+    sfx=""; [ $c != 3 ] && sfx="_cfg$c"
+    python3 $ROOT/scripts/pmc_step_traffic.py "$fr" "$fw" > $OUT/${R}_step_traffic_pmc$sfx.csv 2> $OUT/${R}_step_traffic$sfx.err
   done
-  fr=$(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
-  fw=$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
-  python3 $ROOT/scripts/pmc_step_traffic.py "$fr" "$fw" > $OUT/${R}_step_traffic_pmc.csv 2> $OUT/${R}_step_traffic.err
   # counter calibration on a transfer of known size (MI355X_MICROARCH.md: WRITE_SIZE is uncalibrated)
   rm -rf /tmp/pmc_cal
   GB_WRITE_BW=1 GB_ITERS=1 GB_ROUNDS=1 timeout 120 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmc_cal -o p --output-format csv -- $ROOT/scripts/probe/_probe_gemm_bench $ROOT/scripts/gemm_shapes_pmc.txt > /dev/null 2>&1
@@ -66,7 +74,30 @@ if has gemmpmc; then
   cd $ROOT
 fi
 if has rccl; then
+  # the N > 1 call path through a 1-rank RCCL group (reduce-scatter / shard AdamW / all-gather really issued)
   MACAW_FORCE_COLLECTIVES=1 timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${R}_bench_cfg3_1rank_rccl.json 2> $OUT/${R}_bench_rccl.err
-  MACAW_BUCKETED=1 timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${R}_bench_cfg3_bucketed_local.json 2>> $OUT/${R}_bench_rccl.err
+  # ... and two ranks sharing this GPU over gloo (bench.py's N > 1 branch end to end; not a benchmark)
+  MACAW_SHARE_GPU=1 MACAW_DIST_BACKEND=gloo timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+    --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 3 --warmup 1 --batch-per-gpu 8 --no-cpu-baseline \
+    > $OUT/${R}_bench_cfg3_2ranks_1gpu_gloo.json 2>> $OUT/${R}_bench_rccl.err
+fi
+if has parity; then
+  # the measured errors of the full-size parity tests (prints of tests/test_fullsize_gpu.py, test_fp8_gpu.py)
+  timeout 600 python -m pytest tests/test_fullsize_gpu.py tests/test_fp8_gpu.py -m gpu -q -s -p no:cacheprovider 2>&1 \
+    | grep -E "oracle|yardstick|relative errors|real7b|passed|failed" > $OUT/${R}_fullsize_parity.log
+fi
+if has probes; then
+  timeout 300 python scripts/probe/gloo_cuda_race.py 150 1 > $OUT/${R}_probe_gloo_cuda_race.txt 2>&1
+  timeout 300 python scripts/probe/splitk_stress.py 3000 3 1 > $OUT/${R}_probe_splitk_stress.txt 2>&1
+  timeout 600 python scripts/probe/flaky_dp.py 10 > $OUT/${R}_probe_flaky_dp.txt 2>&1
+fi
+if has tail; then
+  for i in 1 2; do
+    MK_GEMM_NO_TAIL8=1 scripts/probe/_probe_gemm_bench scripts/gemm_shapes_tail.txt > $OUT/${R}_gemm_tail_quarters_$i.csv 2> /dev/null
+    scripts/probe/_probe_gemm_bench scripts/gemm_shapes_tail.txt > $OUT/${R}_gemm_tail_eighths_$i.csv 2> /dev/null
+  done
+fi
+if has decode; then
+  timeout 300 python scripts/bench_generate.py > $OUT/${R}_generate.txt 2>&1
 fi
 ls -la $OUT | grep "${R}_" | head -40
