@@ -624,6 +624,7 @@ class MHASelfFn(torch.autograd.Function):
         out = ops.linear_fwd(att, out_w, bias=out_b)
         ctx.save_for_backward(x2, q, kv, probs, pd, att, in_w, out_w)
         ctx.dims = (B, L, E, H, hd, p, seed)
+        ctx.in_b_ref, ctx.out_b_ref = in_b, out_b        # (only their addresses are used: gradient-bucket lookup)
         return out.view(B, L, E)
 
     @staticmethod
@@ -634,7 +635,7 @@ class MHASelfFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dout2 = _c2(dout, B * L, E)
         datt = ops.linear_dx(dout2, out_w)
-        dwo, dbo = ops.linear_dw(dout2, att), ops.colsum(dout2)
+        dwo, dbo = ops.linear_dw(dout2, att, w=out_w), ops.colsum(dout2, out=ops.grad_dst(ctx.out_b_ref))
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         kd, vd = TDesc(kv, 2 * E, Lk * 2 * E, 0), TDesc(kv, 2 * E, Lk * 2 * E, E)
@@ -652,8 +653,12 @@ class MHASelfFn(torch.autograd.Function):
         # compact the projected rows [B, L, 2E] (drop the 2 extra rows per sample)
         dkvc = torch.empty((B * L, 2 * E), dtype=x2.dtype, device=x2.device)
         ops.copy2d(rows, dkvc, L, 2 * E, 2 * E, 2 * E, batch=B, s_src=Lk * 2 * E, s_dst=L * 2 * E)
-        din_w = torch.empty_like(in_w)
-        din_b = torch.empty((3 * E,), dtype=x2.dtype, device=x2.device)
+        din_w = ops.grad_dst(in_w)
+        if din_w is None:
+            din_w = torch.empty_like(in_w)
+        din_b = ops.grad_dst(ctx.in_b_ref)
+        if din_b is None:
+            din_b = torch.empty((3 * E,), dtype=x2.dtype, device=x2.device)
         ops.linear_dw(dq, x2, out=din_w[:E])
         ops.linear_dw(dkvc, x2, out=din_w[E:])
         ops.colsum(dq, out=din_b[:E])

@@ -254,11 +254,12 @@ def grad_dst(w):
     if not GRAD_DST or w is None:
         return None
     d = GRAD_DST.get((w.data_ptr(), w.numel()))
-    if d is not None and d.dtype == w.dtype:
-        if d.shape == w.shape:
-            return d
-        if d.numel() == w.numel() and w.is_contiguous():
-            return d.view(w.shape)
+    if d is not None and d.dtype == w.dtype and d.numel() == w.numel() and (d.shape == w.shape or w.is_contiguous()):
+        # a FRESH view object every time: autograd's AccumulateGrad takes a returned gradient as p.grad
+        # without copying only if nobody else references that tensor object -- handing out the
+        # dictionary's own tensor made it clone every such gradient (and the hook copy it back):
+        # ~150 hidden device copies + ~150 copy-backs per step in round 2's "direct" path
+        return d.view(w.shape)
     return None
 
 
