@@ -357,7 +357,12 @@ def main():
     # ZeRO-1; a failure at N = 1 is an error.  (A rank that dies ALONE leaves the others inside a
     # collective; that ends at the process group's watchdog timeout, as in any RCCL job.)
     degraded = None
-    side_group = dist.new_group(backend="gloo") if (world > 1 and dist.get_backend() != "gloo") else None
+    side_group = None
+    if world > 1 and dist.get_backend() != "gloo":
+        try:
+            side_group = dist.new_group(backend="gloo")
+        except Exception as e:      # noqa: BLE001  (no usable TCP interface for gloo: agree over the default group)
+            print(f"[bench] rank {rank}: no gloo side group ({e!r}); the setup verdict travels over RCCL", file=sys.stderr)
     err = None
     inject = os.environ.get("MACAW_BENCH_INJECT_FAIL")     # test hook: "all" fails every rank's ZeRO-1 setup step
     try:
@@ -370,7 +375,8 @@ def main():
             raise
         err = repr(e)[:300]
     if world > 1:
-        flag = torch.tensor([1 if err else 0], dtype=torch.int32)
+        on_dev = side_group is None and dist.get_backend() != "gloo"
+        flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev if on_dev else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=side_group)
         if int(flag.item()):
             degraded = err or "the setup step failed on another rank"

@@ -90,7 +90,8 @@ typedef struct mk_gemm_desc {
 #define MK_GEMM_SCALE_VEC 4   /* scale_a / scale_b are VECTORS: scale_a[M] per row of A (= output row),
                                  scale_b[N] per row of B (= output column): C = alpha-free
                                  act(acc * scale_a[m] * scale_b[n] + bias) ... (per-row / per-channel
-                                 fp8 de-quantisation, mk_fp8_quantize_rows / _cols_t) */
+                                 fp8 de-quantisation, mk_fp8_quantize_rows / _cols_t); MK_FP8_E4M3
+                                 operands only, MK_ERR_UNSUPPORTED otherwise */
 #define MK_GEMM_A_KPAD_ZERO 1
 #define MK_GEMM_B_KPAD_ZERO 2
 int mk_gemm(const mk_gemm_desc* d, void* stream);

@@ -368,6 +368,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
   g.scale_a = d->scale_a; g.scale_b = d->scale_b;
   g.scale_vec = (d->flags & MK_GEMM_SCALE_VEC) ? 1 : 0;
   if (g.scale_vec && (!d->scale_a || !d->scale_b)) return MK_ERR_BAD_ARG;
+  if (g.scale_vec && !fp8) return MK_ERR_UNSUPPORTED;   // per-row / per-column scales exist in the e4m3 instantiations only
   g.A = d->A; g.B = d->B; g.C = d->C; g.R = d->R; g.bias = d->bias;
   g.M = d->M; g.N = d->N; g.K = d->K;
   g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldr = d->ldr;

@@ -69,7 +69,10 @@ MK_DEV void tile_from_index(int wg, int tiles_m, int tiles_n, int& tm, int& tn, 
 // fp32 in its private 8 KiB (float4 index XOR row: conflict-free both ways), reads them back
 // row-major -- 16 lanes per 64-column row -- and every load / store is a full 128-byte line per
 // row; the residual rows of a pass group are all requested before the first is used.
-template <typename ET, int FM, int FN>
+// SV: per-row x per-column de-quantisation scales (g.scale_vec) are compiled in -- the fp8 instantiations
+// only: carried as a run-time branch the four column scales and the row-scale pointer stay live beside
+// the accumulators and cost every 16-bit v2 kernel its fourth wave per SIMD (125 -> 136-142 VGPRs).
+template <bool SV, typename ET, int FM, int FN>
 MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, ET* C, const ET* Rp,
                           int m0, int n0, int wm0, int wn0, char* smem) {
   typedef typename E16<ET>::x4 e16x4;
@@ -78,7 +81,7 @@ MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, ET* C,
   constexpr int NPASS = 32 / RPI;   // passes per 32-row fragment
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   float alpha = g.alpha;
-  const bool svec = g.scale_vec != 0;
+  const bool svec = SV && g.scale_vec != 0;
   if (!svec) {
     if (g.scale_a) alpha *= g.scale_a[0];
     if (g.scale_b) alpha *= g.scale_b[0];

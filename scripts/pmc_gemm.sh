@@ -29,7 +29,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in sorted(glob.glob(out + '/pass*.csv')):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'][:60]
+        k = r['Kernel_Name'].split('(mkg')[0][-60:]
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         cnt[k][r['Counter_Name']] += 1
 with open(out + '/summary.txt', 'w') as fo:

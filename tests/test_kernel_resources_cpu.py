@@ -1,0 +1,73 @@
+"""Occupancy budgets of the shipped gfx950 kernels, read from the built library's own code-object
+metadata (scripts/kernel_resources.py; no GPU, no recompilation).
+
+Why this exists: in round 3 a run-time branch in the shared GEMM epilogue (per-row / per-column fp8
+scales) raised every 16-bit 128x128 kernel from 125 to 136-142 VGPRs = from four to three waves per
+SIMD, and the BK = 32 instantiations -- LDS leaves room for five workgroups per CU, registers decide --
+lost 12-24 % (profiles/r02_cfg5_last_step.txt vs r03: 11.4 -> 14.1 ms).  Parity tests cannot see that."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts"))
+import kernel_resources as kr  # noqa: E402
+
+LLVM_TOOLS = all(os.path.exists(os.path.join(kr.LLVM, t)) for t in ("llvm-objcopy", "llvm-readelf"))
+pytestmark = pytest.mark.skipif(not (LLVM_TOOLS and os.path.exists(kr.LIB)),
+                                reason="needs the built library and ROCm's llvm-objcopy / llvm-readelf")
+
+
+@pytest.fixture(scope="module")
+def ks():
+    from macaw_llm_amd import build
+    build.build()                       # no-op when the stamp matches the sources
+    return kr.kernels()
+
+
+def _pick(ks, *subs):
+    out = {k: v for k, v in ks.items() if all(s in k for s in subs)}
+    assert out, f"no kernel matches {subs}"
+    return out
+
+
+def test_every_kernel_of_the_library_is_listed_and_both_element_types_exist(ks):
+    assert len(ks) > 200
+    for ns in ("e_bf16::", "e_f16::"):
+        for stem in ("v7_kernel", "v2_kernel", "flash_fwd", "flash_bwd_dkv", "decode_step_attn", "gemm_skinny16"):
+            _pick(ks, ns, stem)
+
+
+def test_the_128x128_gemm_kernels_keep_four_waves_per_simd(ks):
+    """512 VGPRs per SIMD lane / 4 waves = 128.  Matters for BK = 32 (32 KiB of LDS per workgroup: five fit, so
+    registers decide); BK = 64 needs 64 KiB of LDS (two workgroups per CU whatever the registers) -- its NT
+    instantiation is allowed the 140 it has always had."""
+    for k, v in _pick(ks, "gemm_", "_v2_kernel<").items():
+        if "fp8" in k:
+            continue
+        limit = 144 if k.endswith("<false, false, 64>(mkg::GemmArgs)") else 128
+        assert v["vgpr_count"] <= limit, (k, v)
+
+
+def test_the_256x256_gemm_kernels_fit_two_workgroups_of_eight_waves_per_cu(ks):
+    for k, v in _pick(ks, "_v7_kernel<").items():
+        assert v["vgpr_count"] <= 256 and v.get("vgpr_spill_count", 0) == 0, (k, v)
+        assert v.get("private_segment_fixed_size", 0) == 0, (k, v)
+
+
+def test_no_hot_kernel_spills(ks):
+    """one known exception: the non-causal head-dim-128 dq kernel (4 VGPRs, 20 B of scratch; not on any
+    BASELINE configuration's path -- LLaMA is causal, the alignment attention has no backward through it)"""
+    spilled = {k: v for k, v in ks.items() if v.get("vgpr_spill_count", 0)}      # (SGPR -> VGPR-lane spills cost nothing)
+    allowed = [k for k in spilled if "flash_bwd_dq" in k and "<128, false>" in k]
+    unexpected = {k: v for k, v in spilled.items() if k not in allowed}
+    assert not unexpected, unexpected
+
+
+def test_attention_and_streaming_kernels_keep_their_occupancy(ks):
+    for k, v in _pick(ks, "flash_fwd").items():
+        assert v["vgpr_count"] <= 256, (k, v)              # two 4-wave workgroups per SIMD pair
+    for k, v in _pick(ks, "adamw_multi_kernel").items():
+        assert v["vgpr_count"] <= 72, (k, v)               # HBM-bound: >= 7 waves per SIMD in flight
+    for k, v in _pick(ks, "gemm_skinny16_kernel").items():
+        assert v["vgpr_count"] <= 128, (k, v)              # weight streaming: latency hidden by resident waves
