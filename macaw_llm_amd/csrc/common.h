@@ -102,6 +102,11 @@ template <> struct VecIO<float> {
   MK_DEV static void store(float* p, const float (&o)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
   }
+  // the 16 bytes as they are (a load kept in flight across other work) and their conversion later
+  MK_DEV static uint4 load_raw(const float* p) { return *reinterpret_cast<const uint4*>(p); }
+  MK_DEV static void unpack(uint4 r, float (&o)[4]) {
+    o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y); o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
+  }
 };
 template <> struct VecIO<bf16> {
   static constexpr int N = 8;
@@ -115,6 +120,12 @@ template <> struct VecIO<bf16> {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (bf16)o[i];
     *reinterpret_cast<bf16x8*>(p) = v;
+  }
+  MK_DEV static uint4 load_raw(const bf16* p) { return *reinterpret_cast<const uint4*>(p); }
+  MK_DEV static void unpack(uint4 r, float (&o)[8]) {
+    const bf16x8 v = __builtin_bit_cast(bf16x8, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
   }
 };
 
@@ -130,6 +141,12 @@ template <> struct VecIO<_Float16> {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (_Float16)o[i];
     *reinterpret_cast<f16x8*>(p) = v;
+  }
+  MK_DEV static uint4 load_raw(const _Float16* p) { return *reinterpret_cast<const uint4*>(p); }
+  MK_DEV static void unpack(uint4 r, float (&o)[8]) {
+    const f16x8 v = __builtin_bit_cast(f16x8, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
   }
 };
 

@@ -264,6 +264,18 @@ extern "C" int mk_prof_report(const char* path) {
 }
 
 namespace { int g_force_cfg = -1; }
+namespace {
+// kernel for 17 ... 32 token rows: 19 = two 16-token tiles per 16 weight rows (gemm_skinny16_kernel MT = 2),
+// 20 / 21 / 22 = 32 x 32 pipelined (gemm_skinny32p_kernel: 8 waves x 2 K-blocks, 16 waves, 8 waves x 3 buffers);
+// MK_GEMM_SKINNY32 = one of them for every N, 0 / unset = the measured rule
+int skinny32_cfg(int N) {
+  const char* e = getenv("MK_GEMM_SKINNY32");      // read per call: scripts/bench_generate.py switches it in-process
+  const int forced = e ? atoi(e) : 0;
+  if (forced >= 19 && forced <= 22) return forced;
+  (void)N;
+  return 19;
+}
+}
 // tuning / A-B hook (scripts/gemm_bench.cpp, tests): force a kernel configuration for the
 // following mk_gemm calls of this process (-1 = automatic choice); same meaning as MK_GEMM_CFG
 extern "C" int mk_gemm_set_cfg(int cfg) { g_force_cfg = cfg; return MK_OK; }
@@ -295,7 +307,10 @@ extern "C" int mk_decode_linear(const void* x, int64_t ldx, const void* W, int64
   const size_t lds = prologue ? (size_t)M * (K + 8) * 2 : 0;   // prepared token rows
   if (lds > 40 * 1024) return MK_ERR_UNSUPPORTED;   // (two workgroups per CU must still fit)
   const int prof = mkp::begin(st, 0, 2.0 * M * N * K, M, N, K, 1, 0, 17 + 10 * prologue);
-  if (dtype == MK_F16) e_f16::launch_decode_linear(g, M, N, prologue, wide, lds, st);
+  if (M > 16) {                     // (no prologue: checked above) same kernels as mk_gemm's skinny path
+    if (dtype == MK_F16) e_f16::launch_skinny(g, skinny32_cfg(N), N, st);
+    else e_bf16::launch_skinny(g, skinny32_cfg(N), N, st);
+  } else if (dtype == MK_F16) e_f16::launch_decode_linear(g, M, N, prologue, wide, lds, st);
   else e_bf16::launch_decode_linear(g, M, N, prologue, wide, lds, st);
   mkp::end(prof, st);
   return mk_check_launch();
@@ -390,8 +405,8 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     // cfg 12 = 32 weight rows per workgroup (8 waves), 17 / 18 = 16 rows per workgroup with 8 / 16
     // waves splitting K (measured cold, scripts/gemm_shapes_decode.txt: 4.0 ... 5.7 TB/s against
     // 2.1 ... 3.8; 16 waves where N / 16 workgroups alone would leave a CU with one short wave set)
-    int sk = d->M <= 16 ? ((d->N <= 16 * 256 && d->K <= 4096) ? 18 : 17) : 19;
-    if (g_force_cfg >= 12 && g_force_cfg <= 19 && (g_force_cfg == 12 || g_force_cfg == 19 || d->M <= 16)) sk = g_force_cfg;
+    int sk = d->M <= 16 ? ((d->N <= 16 * 256 && d->K <= 4096) ? 18 : 17) : skinny32_cfg(d->N);
+    if (g_force_cfg >= 12 && g_force_cfg <= 22 && (g_force_cfg == 12 || g_force_cfg >= 19 || d->M <= 16)) sk = g_force_cfg;
     mkp::set_cfg(prof, sk);
     if (f16) e_f16::launch_skinny(g, sk, d->N, st);
     else e_bf16::launch_skinny(g, sk, d->N, st);
@@ -477,7 +492,8 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
         // the tail runs as ONE short round on up to all CUs (a 32-tile tail as quarters keeps half
         // of the chip idle for a longer round)
         g.dp_tiles = T - R;
-        g.tail8 = 1;
+        static const bool ns6 = getenv("MK_GEMM_TAIL8_NS6") != nullptr;   // A/B: six packed 24-KiB stages
+        g.tail8 = ns6 ? 2 : 1;
         grid.x = g.dp_tiles + 8 * R;
       } else if (R > 0 && 4 * R <= 2 * n_cus) {
         g.dp_tiles = T - R;

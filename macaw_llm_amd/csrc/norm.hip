@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* x, const T* r
 
 // dx = dres + rstd * (dn - n * mean(dn * n)), dn = dy*w, n = h*rstd.
 // Block b owns rows b, b+nblk, ... and keeps its dw column sums in registers.
-template <typename T, int CH>
+// PF: the three streams of the block's NEXT row are requested (raw 16-byte vectors, converted later) before
+// the block-wide reduction of the current one -- a row is a serial chain load -> reduce (two barriers) ->
+// store, and without the prefetch a block has nothing in flight during the last two links.
+template <typename T, int CH, bool PF>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* h, const T* w,
                                                           const float* rstd, const T* dres, T* dx,
                                                           float* dw_partial, int rows, int cols) {
@@ -77,21 +80,56 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* 
     for (int i = 0; i < N; ++i) { dwacc[k][i] = 0.f; wv[k][i] = 0.f; }
     if (c < nch) VecIO<T>::load(w + c * N, wv[k]);
   }
-  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
-    const float rs = rstd[row];
-    float dyv[CH][N], nv[CH][N], rv[CH][N];
-    float dot = 0.f;
-    // all three streams of the row are requested up front (the residual gradient is only needed
-    // after the block reduction: loading it there exposed one more HBM round trip per row)
+  uint4 qdy[CH], qh[CH], qr[CH];
+  float rs_q = 0.f;
+  // Straight-line requests from CLAMPED addresses (row and chunk), selected to zero afterwards: a load under
+  // `if` sits in its own basic block and the compiler then waits vmcnt(0) right behind it (see
+  // attention_impl.inc ld16_or_zero) -- which is exactly the overlap this prefetch is for.
+  auto fetch = [&](long row) {
+    row = min(row, (long)rows - 1);
+    const T* rsrc = dres ? dres : dy;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
-      const int c = threadIdx.x + 256 * k;
+      const int cc = min((int)threadIdx.x + 256 * k, nch - 1);
+      qdy[k] = VecIO<T>::load_raw(dy + row * cols + cc * N);
+      qh[k] = VecIO<T>::load_raw(h + row * cols + cc * N);
+      qr[k] = VecIO<T>::load_raw(rsrc + row * cols + cc * N);
+    }
+    rs_q = rstd[row];
+  };
+  if constexpr (PF) fetch(blockIdx.x);
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    float rs;
+    float dyv[CH][N], nv[CH][N], rv[CH][N];
+    float dot = 0.f;
+    if constexpr (PF) {
+      rs = rs_q;
 #pragma unroll
-      for (int i = 0; i < N; ++i) rv[k][i] = 0.f;
-      if (c < nch) {
-        VecIO<T>::load(dy + row * cols + c * N, dyv[k]);
-        VecIO<T>::load(h + row * cols + c * N, nv[k]);
-        if (dres) VecIO<T>::load(dres + row * cols + c * N, rv[k]);
+      for (int k = 0; k < CH; ++k) {
+        const bool ok = threadIdx.x + 256 * k < nch;
+        VecIO<T>::unpack(qdy[k], dyv[k]);
+        VecIO<T>::unpack(qh[k], nv[k]);
+        VecIO<T>::unpack(qr[k], rv[k]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          dyv[k][i] = ok ? dyv[k][i] : 0.f;
+          nv[k][i] = ok ? nv[k][i] : 0.f;
+          rv[k][i] = (ok && dres) ? rv[k][i] : 0.f;
+        }
+      }
+      fetch(row + gridDim.x);          // (the last row of the block re-requests row rows - 1: harmless)
+    } else {
+      rs = rstd[row];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int c = threadIdx.x + 256 * k;
+#pragma unroll
+        for (int i = 0; i < N; ++i) rv[k][i] = 0.f;
+        if (c < nch) {
+          VecIO<T>::load(dy + row * cols + c * N, dyv[k]);
+          VecIO<T>::load(h + row * cols + c * N, nv[k]);
+          if (dres) VecIO<T>::load(dres + row * cols + c * N, rv[k]);
+        }
       }
     }
 #pragma unroll
@@ -299,13 +337,16 @@ int rmsnorm_bwd_launch(const void* dy, const void* h, const void* w, const float
   if (cols % N) return MK_ERR_UNSUPPORTED;
   const int ch = mk_cdiv(cols / N, 256);
   dim3 grid(nblk), block(256);
-#define MK_RB(CHV)                                                                             \
-  MK_LAUNCH((rmsnorm_bwd_kernel<T, CHV>), grid, block, 0, st, (const T*)dy, (const T*)h, \
+  // next-row prefetch for the narrow instantiations (ch <= 2: LLaMA widths); the wide ones have no registers
+  // to spare.  MK_RMSNORM_BWD_NO_PREFETCH = the round-2 kernel, for A/B (scripts/bench_norm.py)
+  static const bool pf = getenv("MK_RMSNORM_BWD_NO_PREFETCH") == nullptr;
+#define MK_RB(CHV, PFV)                                                                        \
+  MK_LAUNCH((rmsnorm_bwd_kernel<T, CHV, PFV>), grid, block, 0, st, (const T*)dy, (const T*)h, \
                      (const T*)w, rstd, (const T*)dres, (T*)dx, dwp, rows, cols)
-  if (ch <= 1) MK_RB(1);
-  else if (ch <= 2) MK_RB(2);
-  else if (ch <= 4) MK_RB(4);
-  else if (ch <= 8) MK_RB(8);
+  if (ch <= 1) { if (pf) MK_RB(1, true); else MK_RB(1, false); }
+  else if (ch <= 2) { if (pf) MK_RB(2, true); else MK_RB(2, false); }
+  else if (ch <= 4) MK_RB(4, false);
+  else if (ch <= 8) MK_RB(8, false);
   else return MK_ERR_UNSUPPORTED;
 #undef MK_RB
   return mk_check_launch();

@@ -40,6 +40,24 @@ for step in "$@"; do
       timeout 400 python bench.py --config 4 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_cfg4.json 2> $out/bench_cfg4.err ;;
     bench)
       timeout 600 python bench.py --steps 8 --warmup 3 > $out/bench_cfg3.json 2> $out/bench_cfg3.err ;;
+    exp1)   # round-3 late experiments: 17-32-row decode kernels, six-stage eighth tail, RMSNorm-backward prefetch
+      timeout 500 python -m pytest tests/test_kernels_gpu.py -k "gemm or rmsnorm" -x -q -rf --timeout 240 -p no:cacheprovider > $out/t_kern.log 2>&1
+      echo "pytest rc=$?" >> $out/t_kern.log
+      MK_GEMM_TAIL8_NS6=1 timeout 300 python -m pytest tests/test_kernels_gpu.py tests/test_fp8_gpu.py -k "v7_256 or fp8" -x -q -rf --timeout 240 -p no:cacheprovider > $out/t_ns6.log 2>&1
+      echo "pytest rc=$?" >> $out/t_ns6.log
+      for i in 1 2; do
+        scripts/probe/_probe_gemm_bench scripts/gemm_shapes_tail.txt > $out/tail_ns5_$i.csv 2> $out/tail.err
+        MK_GEMM_TAIL8_NS6=1 scripts/probe/_probe_gemm_bench scripts/gemm_shapes_tail.txt > $out/tail_ns6_$i.csv 2>> $out/tail.err
+      done
+      GB_COLD=1 scripts/probe/_probe_gemm_bench scripts/gemm_shapes_decode32.txt > $out/decode32_cold.csv 2> $out/decode32.err
+      scripts/probe/_probe_gemm_bench scripts/gemm_shapes_decode32.txt > $out/decode32_warm.csv 2>> $out/decode32.err
+      timeout 120 python scripts/bench_norm.py > $out/norm_prefetch.txt 2>&1
+      MK_RMSNORM_BWD_NO_PREFETCH=1 timeout 120 python scripts/bench_norm.py > $out/norm_r2.txt 2>&1
+      BG_SKINNY32=19,20,21,22 timeout 400 python scripts/bench_generate.py 32 24 > $out/generate_skinny32.txt 2>&1
+      timeout 300 python bench.py --config 2 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_cfg2.json 2> $out/bench_cfg2.err
+      timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_cfg3.json 2> $out/bench_cfg3.err
+      MK_GEMM_TAIL8_NS6=1 timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_cfg3_ns6.json 2> $out/bench_cfg3_ns6.err
+      timeout 400 python bench.py --config 5 --steps 3 --warmup 2 --no-cpu-baseline > $out/bench_cfg5.json 2> $out/bench_cfg5.err ;;
     flaky)
       timeout 900 python scripts/probe/flaky_dp.py 8 > $out/flaky.txt 2>&1 ;;
     *) echo "unknown step $step" ;;

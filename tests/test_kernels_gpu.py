@@ -600,6 +600,49 @@ def test_flash_attention_bwd(dev, dtype, hd, Lq, Lk, causal, masked):
         assert torch.isfinite(got).all() and err <= lim, (name, err, lim)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [19, 20, 21, 22])
+@pytest.mark.parametrize("M,N,K", [(32, 4096, 4096), (17, 1000, 1024), (24, 12288, 4096), (32, 250, 192),
+                                   (29, 4096, 11008), (32, 77, 64)])
+def test_gemm_skinny_17_to_32_rows_every_kernel(dev, dtype, cfg, M, N, K):
+    """17 ... 32 token rows: the two-tile 16-row kernel (19) and the three instantiations of the pipelined
+    32 x 32 kernel (20: 8 waves x 2 K-blocks per trip, 21: 16 waves, 22: 8 waves, three buffers) forced in
+    turn -- ragged N (clamped weight rows), K blocks fewer than the waves (nkb = 1, 3), every epilogue
+    option -- against fp32 math on the same inputs; all four must agree with each other within one
+    rounding of the result (same products, different fp32 summation order)."""
+    from macaw_llm_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    x = _rand((M, K), dtype, g)
+    W = (_rand((N, K), dtype, g).float() * 0.05).to(dtype)
+    b = _rand((N,), dtype, g)
+    r = _rand((M, N), dtype, g)
+    xd, Wd = x.to(dev), W.to(dev)
+    ref = x.float() @ W.float().t()
+    try:
+        lib.mk_gemm_set_cfg(cfg)
+        y = ops.linear_fwd(xd, Wd)
+        y2 = ops.linear_fwd(xd, Wd, bias=b.to(dev), act=2, residual=r.to(dev))
+        ldc = (N + 63) // 64 * 64
+        buf = torch.full((M, ldc), float("nan"), dtype=dtype, device=dev)
+        ops.gemm_raw(xd, Wd, buf, M, N, K, K, K, ldc)
+        c0 = _rand((M, N), dtype, g)
+        cd = c0.to(dev).clone()
+        ops.gemm_raw(xd, Wd, cd, M, N, K, K, K, N, accumulate=True, alpha=0.5)
+        lib.mk_gemm_set_cfg(19)
+        y19 = ops.linear_fwd(xd, Wd)
+    finally:
+        lib.mk_gemm_set_cfg(-1)
+    _close(y, ref, dtype, scale=math.sqrt(K) * 0.05, what=f"skinny32 cfg {cfg} plain")
+    pre = ref + b.float()[None]
+    want = pre * torch.sigmoid(1.702 * pre) + r.float()
+    _close(y2, want, dtype, scale=math.sqrt(K) * 0.05 + 1.0, what=f"skinny32 cfg {cfg} bias+quick_gelu+residual")
+    _close(cd, 0.5 * ref + c0.float(), dtype, scale=math.sqrt(K) * 0.05 + 1.0, what=f"skinny32 cfg {cfg} accumulate")
+    assert torch.equal(buf[:, :N], y) and torch.isnan(buf[:, N:].float()).all()       # pitched C, pad untouched
+    ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+    assert (y.float() - y19.float()).abs().max().item() <= ulp * ref.abs().max().item() + 1e-6
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 22016, 4096), (32, 4096, 11008), (5, 107, 128),
                                    (2, 32007, 4096), (31, 250, 192), (16, 4096, 11008), (7, 4000, 1024),
                                    (13, 520, 704), (17, 4096, 4096), (24, 1000, 1024)])
