@@ -9,13 +9,18 @@ model = build_model(cfg, dtype=torch.bfloat16, device=dev, seed=1).eval()
 _w = synthetic_inputs(cfg, 1, 128, modalities=("images", "audios"), seed=2, device=dev)
 with torch.no_grad():
     model.llm.generate(inputs_embeds=model.prepare_inputs_for_generation(_w)[0], max_new_tokens=4, eos_token_id=-1)
-# usage: bench_generate.py [B ...]; BG_SKINNY32="19,20,21,22" repeats every batch size > 16 with each kernel for
-# 17 ... 32 token rows (MK_GEMM_SKINNY32, csrc/gemm.hip)
+# usage: bench_generate.py [B ...]; BG_SKINNY32="19,22" repeats every batch size > 16 with each kernel for
+# 17 ... 32 token rows (MK_GEMM_SKINNY32), BG_W_NT="0,1" every batch size without / with non-temporal weight
+# loads (MK_DECODE_W_NT; both read per call by csrc/gemm.hip, so one process and one model serve all variants)
 BATCHES = [int(a) for a in sys.argv[1:]] or [1, 8, 32]
-VARIANTS = [v for v in os.environ.get("BG_SKINNY32", "").split(",") if v]
-for B, var in [(B, v) for B in BATCHES for v in (VARIANTS if (VARIANTS and B > 16) else [None])]:
-    if var is not None:
-        os.environ["MK_GEMM_SKINNY32"] = var
+SK = [v for v in os.environ.get("BG_SKINNY32", "").split(",") if v]
+NT = [v for v in os.environ.get("BG_W_NT", "").split(",") if v]
+for B, sk, nt in [(B, s, n) for B in BATCHES for s in (SK if (SK and B > 16) else [None]) for n in (NT or [None])]:
+    if sk is not None:
+        os.environ["MK_GEMM_SKINNY32"] = sk
+    if nt is not None:
+        os.environ["MK_DECODE_W_NT"] = nt
+    var = None if (sk is None and nt is None) else f"skinny32 {sk or 'auto'}, w_nt {nt or 'default'}"
     inp = synthetic_inputs(cfg, B, 128, modalities=("images", "audios"), seed=2, device=dev)
     with torch.no_grad():
         emb, am, _ = model.prepare_inputs_for_generation(inp)
@@ -25,5 +30,5 @@ for B, var in [(B, v) for B in BATCHES for v in (VARIANTS if (VARIANTS and B > 1
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             if new == 8: t8 = dt
         per_tok = (dt - t8) / 64
-        print(("" if var is None else f"[skinny32 = {var}] ") + f"B={B:2d}: prompt S={emb.shape[1]}, prefill+8 tok {t8 * 1e3:7.1f} ms, decode {per_tok * 1e3:6.2f} ms/token "
+        print(("" if var is None else f"[{var}] ") + f"B={B:2d}: prompt S={emb.shape[1]}, prefill+8 tok {t8 * 1e3:7.1f} ms, decode {per_tok * 1e3:6.2f} ms/token "
               f"= {B / per_tok:7.0f} tokens/s (weights streamed once per token: {13.5 / per_tok / 1e3:4.2f} TB/s)")

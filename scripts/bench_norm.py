@@ -1,5 +1,5 @@
 """RMSNorm backward (+ its partial-sum reduction) at the cfg-3 shape, per number of row-slab blocks
-(ops.NORM_BLOCKS): rows are processed one after the other inside a block with a block-wide reduction each,
+(ops.RMSNORM_BLOCKS): rows are processed one after the other inside a block with a block-wide reduction each,
 so the blocks per CU decide how many rows are in flight.  usage: python scripts/bench_norm.py [rows] [cols]"""
 import os
 import sys
@@ -23,8 +23,8 @@ for i in range(NB):
 w = torch.randn((cols,), generator=g).to(torch.bfloat16).to(dev)
 rstd = torch.rand((rows,), generator=g).to(dev) + 0.5
 ref = None
-for nb in (256, 512, 768, 1024, 2048):
-    ops.NORM_BLOCKS = nb
+for nb in (128, 192, 256, 320, 384, 512, 1024):
+    ops.RMSNORM_BLOCKS = nb
     dx, dw = ops.rmsnorm_bwd(*sets[0][:2], w, rstd, dres=sets[0][2])
     if ref is None:
         ref = (dx.clone(), dw.float().clone())
@@ -44,4 +44,4 @@ for nb in (256, 512, 768, 1024, 2048):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (5 * NB)
     gb = rows * cols * 2 * 4 / 1e9          # dy, h, dres read + dx written
-    print(f"NORM_BLOCKS {nb:5d}: {us:7.1f} us per rmsnorm_bwd + colsum_partials, {gb / us * 1e6 / 1e3:5.2f} TB/s of algorithmic bytes", flush=True)
+    print(f"RMSNORM_BLOCKS {nb:5d}: {us:7.1f} us per rmsnorm_bwd + colsum_partials, {gb / us * 1e6 / 1e3:5.2f} TB/s of algorithmic bytes", flush=True)

@@ -58,6 +58,22 @@ for step in "$@"; do
       timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_cfg3.json 2> $out/bench_cfg3.err
       MK_GEMM_TAIL8_NS6=1 timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_cfg3_ns6.json 2> $out/bench_cfg3_ns6.err
       timeout 400 python bench.py --config 5 --steps 3 --warmup 2 --no-cpu-baseline > $out/bench_cfg5.json 2> $out/bench_cfg5.err ;;
+    exp2)   # decode: kernel per N at 17-32 rows, non-temporal weight loads; RMSNorm-backward block sweep
+      timeout 300 python -m pytest tests/test_kernels_gpu.py -k "skinny or rmsnorm or decode" -x -q -rf --timeout 240 -p no:cacheprovider > $out/t_kern.log 2>&1
+      echo "pytest rc=$?" >> $out/t_kern.log
+      MK_DECODE_W_NT=1 timeout 300 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -k "skinny or decode or generate" -x -q -rf --timeout 240 -p no:cacheprovider > $out/t_nt.log 2>&1
+      echo "pytest rc=$?" >> $out/t_nt.log
+      for nt in 0 1; do
+        MK_DECODE_W_NT=$nt GB_COLD=1 scripts/probe/_probe_gemm_bench scripts/gemm_shapes_decode32.txt > $out/decode32_cold_nt$nt.csv 2> $out/decode32.err
+        MK_DECODE_W_NT=$nt GB_COLD=1 scripts/probe/_probe_gemm_bench scripts/gemm_shapes_decode.txt > $out/decode_cold_nt$nt.csv 2>> $out/decode32.err
+      done
+      timeout 120 python scripts/bench_norm.py > $out/norm_sweep.txt 2>&1
+      BG_W_NT=0,1 timeout 400 python scripts/bench_generate.py 1 8 16 32 > $out/generate_nt.txt 2>&1
+      export TMPDIR=/tmp
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d /tmp/dec32 -o d --output-format csv -- python $OLDPWD/scripts/decode_once.py 32 > /dev/null 2>&1)
+      f=$(find /tmp/dec32 -name '*kernel_trace.csv' | head -1)
+      [ -n "$f" ] && python scripts/decode_trace.py "$f" > $out/decode_step_B32.txt 2>&1
+      timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_cfg3.json 2> $out/bench_cfg3.err ;;
     flaky)
       timeout 900 python scripts/probe/flaky_dp.py 8 > $out/flaky.txt 2>&1 ;;
     *) echo "unknown step $step" ;;
