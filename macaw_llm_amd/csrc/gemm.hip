@@ -266,22 +266,16 @@ extern "C" int mk_prof_report(const char* path) {
 namespace { int g_force_cfg = -1; }
 namespace {
 // kernel for 17 ... 32 token rows: 19 = two 16-token tiles per 16 weight rows (gemm_skinny16_kernel MT = 2: N / 16
-// workgroups), 22 = 32 x 32 pipelined (gemm_skinny32p_kernel, 8 waves x 3 buffers: N / 32 workgroups, ONE token
-// byte from L2 per weight byte instead of two), 23 / 24 = variants of 19 (three buffers; 16 waves).  Measured
-// cold (scripts/gemm_shapes_decode32.txt, profiles/r03_decode32_cold.csv): 22 wins where N / 32 still fills
-// the chip (N = 22016: 52 vs 69 us, 32007: 73 vs 91, 12288: 35 vs 37), 19 where it does not (N = 4096: 128
-// workgroups; 14.5 vs 18.2 us at K = 4096, 33.6 vs 46.2 at K = 11008).  MK_GEMM_SKINNY32 forces one (read per
-// call: scripts/bench_generate.py switches it in-process).
+// workgroups), 22 = 32 x 32 pipelined (gemm_skinny32p_kernel: N / 32 workgroups, ONE token byte from L2 per weight
+// byte instead of two).  Measured cold (scripts/gemm_shapes_decode32.txt, profiles/r03_decode32_cold.csv): 22
+// wins where N / 32 still fills the chip (N = 22016: 52 vs 69 us, 32007: 73 vs 91, 12288: 35 vs 37), 19 where it
+// does not (N = 4096 = 128 workgroups: 14.5 vs 18.2 us at K = 4096, 33.6 vs 46.2 at K = 11008).
+// MK_GEMM_SKINNY32 forces one (read per call: scripts/bench_generate.py switches it in-process).
 int skinny32_cfg(int N) {
   const char* e = getenv("MK_GEMM_SKINNY32");
   const int forced = e ? atoi(e) : 0;
-  if (forced == 19 || (forced >= 22 && forced <= 24)) return forced;
+  if (forced == 19 || forced == 22) return forced;
   return N >= 8192 ? 22 : 19;
-}
-// non-temporal weight loads in the decode-step kernels (MK_DECODE_W_NT = 0 / 1, read per call)
-bool decode_w_nt() {
-  const char* e = getenv("MK_DECODE_W_NT");
-  return e ? atoi(e) != 0 : false;
 }
 }
 
@@ -317,10 +311,10 @@ extern "C" int mk_decode_linear(const void* x, int64_t ldx, const void* W, int64
   if (lds > 40 * 1024) return MK_ERR_UNSUPPORTED;   // (two workgroups per CU must still fit)
   const int prof = mkp::begin(st, 0, 2.0 * M * N * K, M, N, K, 1, 0, 17 + 10 * prologue);
   if (M > 16) {                     // (no prologue: checked above) same kernels as mk_gemm's skinny path
-    if (dtype == MK_F16) e_f16::launch_skinny(g, skinny32_cfg(N), N, decode_w_nt(), st);
-    else e_bf16::launch_skinny(g, skinny32_cfg(N), N, decode_w_nt(), st);
-  } else if (dtype == MK_F16) e_f16::launch_decode_linear(g, N, prologue, wide, lds, decode_w_nt(), st);
-  else e_bf16::launch_decode_linear(g, N, prologue, wide, lds, decode_w_nt(), st);
+    if (dtype == MK_F16) e_f16::launch_skinny(g, skinny32_cfg(N), N, st);
+    else e_bf16::launch_skinny(g, skinny32_cfg(N), N, st);
+  } else if (dtype == MK_F16) e_f16::launch_decode_linear(g, N, prologue, wide, lds, st);
+  else e_bf16::launch_decode_linear(g, N, prologue, wide, lds, st);
   mkp::end(prof, st);
   return mk_check_launch();
 }
@@ -415,11 +409,11 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     // waves splitting K (measured cold, scripts/gemm_shapes_decode.txt: 4.0 ... 5.7 TB/s against
     // 2.1 ... 3.8; 16 waves where N / 16 workgroups alone would leave a CU with one short wave set)
     int sk = d->M <= 16 ? ((d->N <= 16 * 256 && d->K <= 4096) ? 18 : 17) : skinny32_cfg(d->N);
-    if (g_force_cfg >= 12 && g_force_cfg <= 24 && g_force_cfg != 20 && g_force_cfg != 21 &&
-        (g_force_cfg == 12 || g_force_cfg >= 19 || d->M <= 16)) sk = g_force_cfg;
+    if ((g_force_cfg == 12 || g_force_cfg == 19 || g_force_cfg == 22) ||
+        ((g_force_cfg == 13 || g_force_cfg == 17 || g_force_cfg == 18) && d->M <= 16)) sk = g_force_cfg;
     mkp::set_cfg(prof, sk);
-    if (f16) e_f16::launch_skinny(g, sk, d->N, decode_w_nt(), st);
-    else e_bf16::launch_skinny(g, sk, d->N, decode_w_nt(), st);
+    if (f16) e_f16::launch_skinny(g, sk, d->N, st);
+    else e_bf16::launch_skinny(g, sk, d->N, st);
     mkp::end(prof, st);
     return mk_check_launch();
   }

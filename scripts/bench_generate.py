@@ -10,17 +10,13 @@ _w = synthetic_inputs(cfg, 1, 128, modalities=("images", "audios"), seed=2, devi
 with torch.no_grad():
     model.llm.generate(inputs_embeds=model.prepare_inputs_for_generation(_w)[0], max_new_tokens=4, eos_token_id=-1)
 # usage: bench_generate.py [B ...]; BG_SKINNY32="19,22" repeats every batch size > 16 with each kernel for
-# 17 ... 32 token rows (MK_GEMM_SKINNY32), BG_W_NT="0,1" every batch size without / with non-temporal weight
-# loads (MK_DECODE_W_NT; both read per call by csrc/gemm.hip, so one process and one model serve all variants)
+# 17 ... 32 token rows (MK_GEMM_SKINNY32, read per call by csrc/gemm.hip: one process and one model serve all variants)
 BATCHES = [int(a) for a in sys.argv[1:]] or [1, 8, 32]
 SK = [v for v in os.environ.get("BG_SKINNY32", "").split(",") if v]
-NT = [v for v in os.environ.get("BG_W_NT", "").split(",") if v]
-for B, sk, nt in [(B, s, n) for B in BATCHES for s in (SK if (SK and B > 16) else [None]) for n in (NT or [None])]:
+for B, sk in [(B, s) for B in BATCHES for s in (SK if (SK and B > 16) else [None])]:
     if sk is not None:
         os.environ["MK_GEMM_SKINNY32"] = sk
-    if nt is not None:
-        os.environ["MK_DECODE_W_NT"] = nt
-    var = None if (sk is None and nt is None) else f"skinny32 {sk or 'auto'}, w_nt {nt or 'default'}"
+    var = None if sk is None else f"skinny32 {sk}"
     inp = synthetic_inputs(cfg, B, 128, modalities=("images", "audios"), seed=2, device=dev)
     with torch.no_grad():
         emb, am, _ = model.prepare_inputs_for_generation(inp)

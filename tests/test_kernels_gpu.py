@@ -601,13 +601,13 @@ def test_flash_attention_bwd(dev, dtype, hd, Lq, Lk, causal, masked):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("cfg", [19, 22, 23, 24])
+@pytest.mark.parametrize("cfg", [19, 22])
 @pytest.mark.parametrize("M,N,K", [(32, 4096, 4096), (17, 1000, 1024), (24, 12288, 4096), (32, 250, 192),
                                    (29, 4096, 11008), (32, 77, 64)])
 def test_gemm_skinny_17_to_32_rows_every_kernel(dev, dtype, cfg, M, N, K):
-    """17 ... 32 token rows: the two-tile 16-row kernel (19; 23 / 24 = its three-buffer and 16-wave variants)
-    and the pipelined 32 x 32 kernel (22) forced in turn -- ragged N (clamped weight rows), K blocks fewer than the waves (nkb = 1, 3), every epilogue
-    option -- against fp32 math on the same inputs; all four must agree with each other within one
+    """17 ... 32 token rows: the two-tile 16-row kernel (19) and the pipelined 32 x 32 kernel (22) forced in
+    turn (mk_gemm picks by N) -- ragged N (clamped weight rows), K blocks fewer than the waves (nkb = 1, 3), every epilogue
+    option -- against fp32 math on the same inputs; the two must agree with each other within one
     rounding of the result (same products, different fp32 summation order)."""
     from macaw_llm_amd import lib as L
     lib = L.load()
