@@ -31,6 +31,24 @@ FULL_GRAD_KEYS = (
 )
 
 
+def reference_greedy(llm, inputs_embeds, max_new_tokens, eos, pad):
+    """greedy decode through the reference's own cached forward; returns new token ids [B, <= max_new_tokens]"""
+    out = llm(inputs_embeds=inputs_embeds, use_cache=True)
+    B = inputs_embeds.shape[0]
+    done = torch.zeros(B, dtype=torch.bool)
+    ids = []
+    for _ in range(max_new_tokens):
+        nxt = out.logits[:, -1, :].argmax(-1)
+        nxt = torch.where(done, torch.full_like(nxt, pad), nxt)
+        ids.append(nxt)
+        done = done | (nxt == eos)
+        if bool(done.all()):
+            break
+        step = llm.prepare_inputs_for_generation(nxt.unsqueeze(1), past_key_values=out.past_key_values, use_cache=True)
+        out = llm(**step)
+    return torch.stack(ids, dim=1)
+
+
 def make(name, cfg_name, batch, text_len, modalities, pad_tail, seed=1234, with_generate=False):
     cfg = configs.get(cfg_name)
     model = ref_loader.build_reference_model(cfg, seed=seed)
@@ -57,9 +75,18 @@ def make(name, cfg_name, batch, text_len, modalities, pad_tail, seed=1234, with_
         no_grad_params=sorted(n for n, p in model.named_parameters() if p.requires_grad and p.grad is None),
     )
     if with_generate:
+        # HF 5.x has no GenerationMixin on the reference's LlamaForCausalLM, so the greedy LOOP
+        # (argmax, pad after eos: transformers 4.29 `greedy_search`) is ours -- but every step is the
+        # REFERENCE's own arithmetic: its forward with its KV cache (modeling.py:183-195) and its
+        # `prepare_inputs_for_generation` (:624-659).  The restated full-recompute loop must give the same ids.
         with torch.no_grad():
-            fx["generate_ids"] = restate.greedy_generate(sd, emb.detach(), cfg, max_new_tokens=8,
-                                                         eos=2, pad=cfg["tags"]["pad"])
+            ids_ref = reference_greedy(model.llm, emb.detach(), max_new_tokens=8, eos=2, pad=cfg["tags"]["pad"])
+            ids_restated = restate.greedy_generate(sd, emb.detach(), cfg, max_new_tokens=8,
+                                                   eos=2, pad=cfg["tags"]["pad"])
+        if not torch.equal(ids_ref, ids_restated):
+            raise SystemExit(f"restated greedy loop disagrees with the reference's cached decode:\n{ids_ref}\n{ids_restated}")
+        fx["generate_ids"] = ids_ref
+        fx["generate_ids_source"] = "reference LlamaForCausalLM.forward + past_key_values, greedy loop of make_golden.reference_greedy"
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     path = os.path.join(GOLDEN_DIR, name + ".pt")
     torch.save(fx, path)

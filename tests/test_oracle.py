@@ -81,7 +81,27 @@ def test_greedy_generate_matches_golden():
     assert torch.equal(ids, fx["generate_ids"])
 
 
+def test_generate_golden_is_the_reference_cached_decode():
+    """the committed ids were produced by the REFERENCE's forward with its own KV cache and its
+    `prepare_inputs_for_generation` (oracle/make_golden.reference_greedy); the restated loop above only
+    reproduces them"""
+    fx = load_case("micro_all")
+    assert fx["generate_ids_source"].startswith("reference LlamaForCausalLM.forward + past_key_values")
+
+
 needs_ref = pytest.mark.skipif(not ref_loader.reference_available(), reason="/root/reference absent")
+
+
+@needs_ref
+def test_reference_cached_decode_reproduces_the_committed_ids():
+    """here, where /root/reference exists: drive the reference's cached forward again and compare with the fixture"""
+    from oracle import make_golden
+    fx = load_case("micro_all")
+    cfg = configs.get(fx["config_name"])
+    model = ref_loader.build_reference_model(cfg, seed=fx["seed"])
+    with torch.no_grad():
+        ids = make_golden.reference_greedy(model.llm, fx["inputs_embeds"], max_new_tokens=8, eos=2, pad=cfg["tags"]["pad"])
+    assert torch.equal(ids, fx["generate_ids"])
 
 
 @needs_ref
