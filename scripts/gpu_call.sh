@@ -74,6 +74,10 @@ for step in "$@"; do
       f=$(find /tmp/dec32 -name '*kernel_trace.csv' | head -1)
       [ -n "$f" ] && python scripts/decode_trace.py "$f" > $out/decode_step_B32.txt 2>&1
       timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_cfg3.json 2> $out/bench_cfg3.err ;;
+    final)  # end-of-round evidence from the final binary: the full GPU suite, then profile_round.sh r03f
+      timeout 900 python -m pytest tests -m gpu -q -rf -s --timeout 240 --durations=8 -p no:cacheprovider > gpurun_out/r03f_gpu_tests.log 2>&1
+      echo "pytest rc=$?" >> gpurun_out/r03f_gpu_tests.log
+      bash scripts/profile_round.sh r03f bench prof traffic3 decode > gpurun_out/r03f_profile.log 2>&1 ;;
     flaky)
       timeout 900 python scripts/probe/flaky_dp.py 8 > $out/flaky.txt 2>&1 ;;
     *) echo "unknown step $step" ;;

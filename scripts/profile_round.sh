@@ -37,11 +37,13 @@ if has prof || has prof3; then
     cd $ROOT
   done
 fi
-if has traffic; then
+TRAFFIC_CFGS="3 2 4 5"
+has traffic3 && TRAFFIC_CFGS="3"
+if has traffic || has traffic3; then
   cd /tmp
   # one pair of --pmc passes per configuration (bench.py reports `roofline.traffic` only from a PMC
   # profile of the SAME configuration): cfg 3 -> _step_traffic_pmc.csv, cfg N -> _step_traffic_pmc_cfgN.csv
-  for c in 3 2 4 5; do
+  for c in $TRAFFIC_CFGS; do
     for ctr in FETCH_SIZE WRITE_SIZE; do
       rm -rf /tmp/pmc_$ctr
       timeout 600 rocprofv3 --pmc $ctr -d /tmp/pmc_$ctr -o p --output-format csv -- python $ROOT/bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${R}_pmc_${ctr}_cfg$c.err
