@@ -288,7 +288,8 @@ int mk_argmax_rows(const void* x, int64_t ld, int32_t rows, int32_t cols, int64_
  *   [K], eps: y = (norm_w * rnd(x * rstd)) W^T, modeling.py:100-105); 2 = SwiGLU (x [M][2K] =
  *   [gate | up]: (rnd(silu(gate)) * up) W^T, modeling.py:140).  With a prologue the prepared token rows
  *   are staged in LDS: M * (K + 8) * 2 bytes <= 40 KiB, else MK_ERR_UNSUPPORTED (use the separate
- *   kernels). */
+ *   kernels).  17 <= M <= 32: 32 weight rows x 32 token rows per workgroup where N >= 8192, two
+ *   16-token tiles per 16 weight rows below (the same choice mk_gemm makes for M <= 32). */
 int mk_decode_linear(const void* x, int64_t ldx, const void* W, int64_t ldw, void* y, int64_t ldy,
                      const void* residual, int64_t ldr, int32_t M, int32_t N, int32_t K,
                      int32_t prologue, const void* norm_w, float eps, int32_t dtype, void* stream);
