@@ -66,6 +66,10 @@ CONFIGS = {
 }
 
 
+# BASELINE.json's metric, verbatim (the N of "at 1/2/4/8 MI355X" is this line's n_gpus)
+METRIC = "multimodal samples/sec (img+audio+128 tok) fwd+bwd at 1/2/4/8 MI355X"
+
+
 def pmc_gemm_traffic(config: int):
     """(bytes, source file) -- HBM-side bytes per mk_gemm launch from the committed rocprofv3 --pmc
     passes of this same command FOR THIS CONFIGURATION (profiles/rNN_step_traffic_pmc[_cfgK].csv:
@@ -428,7 +432,7 @@ def main():
             return {"achieved": round(tf, 1), "frac": round(tf * 1e12 / MFMA_BF16_PEAK, 4), "ms_per_step": round(ms, 3),
                     "launches_per_step": n}
         line = {
-            "metric": "multimodal samples/sec (img+audio+128 tok) fwd+bwd",
+            "metric": METRIC,
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,

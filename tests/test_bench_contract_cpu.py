@@ -1,0 +1,71 @@
+"""bench.py's output contract, checked on CPU against the committed lines of the final binary
+(profiles/r03f_bench_cfg*.json) and on the pieces of bench.py that run without a GPU: the JSON keys the driver
+parses, the roofline / cpu_baseline objects, the per-configuration PMC traffic lookup (never a number measured
+on another configuration), BASELINE.json's metric name."""
+import importlib.util
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)          # main() is guarded by __name__
+    return m
+
+
+def _line(name):
+    with open(os.path.join(PROF, name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name", ["r03f_bench_cfg3.json", "r03f_bench_cfg2.json", "r03f_bench_cfg4.json",
+                                  "r03f_bench_cfg5.json"])
+def test_committed_bench_lines_carry_the_contract(name):
+    d = _line(name)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    # (the committed lines predate the verbatim metric string: they carry it without the " at 1/2/4/8 MI355X" tail)
+    assert base["metric"].startswith(d["metric"]) and d["unit"] == "samples/s"
+    assert _bench().METRIC == base["metric"]
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None                       # BASELINE.md holds no published number for this metric
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["n_gpus"] * d["config"]["per_gpu_batch"] / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert 0.2 < r["frac"] < 1.0
+    if "fp8_gemms" not in r:                              # one peak: frac = achieved / peak
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
+    assert r["launches_per_step"] > 500 and r["gemm_ms_per_step"] < d["ms_per_step"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "samples/s" and c["value"] > 0 and c["sample"]
+
+
+def test_traffic_is_looked_up_per_configuration_and_null_without_a_profile():
+    b = _bench()
+    t3, src3 = b.pmc_gemm_traffic(3)
+    t2, src2 = b.pmc_gemm_traffic(2)
+    t4, src4 = b.pmc_gemm_traffic(4)
+    assert src3 == "r03f_step_traffic_pmc.csv" and "cfg2" in src2 and "cfg4" in src4
+    assert len({t3, t2, t4}) == 3 and all(3e8 < t < 2e9 for t in (t3, t2, t4))     # bytes per launch
+    assert b.pmc_gemm_traffic(5) == (None, None)          # the 13B PMC run aborts: no committed profile
+    assert _line("r03f_bench_cfg3.json")["roofline"]["traffic"] == 720689655 or \
+        _line("r03f_bench_cfg3.json")["roofline"]["traffic"] == t3               # (line printed before / after the r03f profile)
+    assert _line("r03f_bench_cfg5.json")["roofline"]["traffic"] is None
+
+
+def test_configs_match_baseline_json():
+    b = _bench()
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert sorted(b.CONFIGS) == [2, 3, 4, 5]
+    assert len(base["configs"]) >= 5
+    assert b.CONFIGS[3]["batch"] == 32 and b.CONFIGS[3]["seq"] == 144
+    assert b.CONFIGS[4]["seq"] == 2048 and b.CONFIGS[5]["model"] == "real_13b" and b.CONFIGS[5]["fp8"]
