@@ -15,7 +15,6 @@ tensor is ~42 MB per layer; a fused flash kernel for S = 2048 (cfg 4) is a later
 from __future__ import annotations
 
 import math
-from typing import Optional
 
 import torch
 

@@ -19,7 +19,7 @@ Each function cites the reference lines it follows (paths relative to /root/refe
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 import torch.nn.functional as F
