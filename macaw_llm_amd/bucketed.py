@@ -41,6 +41,11 @@ accumulation 3, gradient clipping, cosine schedule with 3 % warm-up).  On MI355X
   * `max_grad_norm`: global-norm clipping as HF Trainer / DeepSpeed do it: the reduce-scatters still
     overlap the backward, the updates wait for the global norm (sum of the shard norms^2 +
     one scalar all-reduce) and take the clip factor as AdamW's grad_scale.
+  * `loss_scaler=DynamicLossScaler()`: fp16 training as the reference's DeepSpeed fp16 block does it
+    (configs/deepspeed_config.json:14-21: loss_scale 0 = dynamic, initial 2^16, window 1000, hysteresis 2,
+    min 1): multiply the loss by `loss_scale` (or use `scale_loss()`), the gradients are unscaled in fp32
+    inside AdamW; a step whose rank-mean gradients are not finite is SKIPPED on every rank (same global
+    test: the sum of the shard norms^2) and the scale backs off.
   * learning-rate schedule: `set_lr()` per step; `cosine_with_warmup()` is HF's
     get_cosine_schedule_with_warmup (train.sh: --lr_scheduler_type cosine --warmup_ratio 0.03).
   * `zero1=False`: all-reduce of each bucket + replicated update (the plain-DDP form; bench.py's
@@ -79,6 +84,43 @@ def shard_batch(global_batch: int, rank: int, world: int):
         raise ValueError(f"global batch {global_batch} not divisible by world size {world}")
     per = global_batch // world
     return rank * per, (rank + 1) * per
+
+
+class DynamicLossScaler:
+    """deepspeed.runtime.fp16.loss_scaler.DynamicLossScaler with the reference's settings as defaults
+    (configs/deepspeed_config.json:14-21).  update(overflow) after every optimizer step attempt:
+    overflow -> the step was skipped; the scale is halved once the hysteresis is used up (floor min_scale);
+    otherwise every `window` steps since the last overflow the scale doubles."""
+
+    def __init__(self, init_scale: float = 2.0 ** 16, scale_factor: float = 2.0, window: int = 1000,
+                 hysteresis: int = 2, min_scale: float = 1.0, consecutive_hysteresis: bool = False):
+        self.scale = float(init_scale)
+        self.factor = float(scale_factor)
+        self.window = int(window)
+        self.hysteresis = int(hysteresis)
+        self.min_scale = float(min_scale)
+        self.consecutive_hysteresis = bool(consecutive_hysteresis)
+        self.cur_hysteresis = int(hysteresis)
+        self.cur_iter = 0
+        self.last_overflow_iter = -1
+        self.skipped = 0
+
+    def update(self, overflow: bool):
+        if overflow:
+            if self.hysteresis == 1 or self.cur_hysteresis == 1:
+                self.scale = max(self.scale / self.factor, self.min_scale)
+            else:
+                self.cur_hysteresis -= 1
+            self.last_overflow_iter = self.cur_iter
+            self.skipped += 1
+        else:
+            if self.consecutive_hysteresis:
+                self.cur_hysteresis = self.hysteresis
+            if (self.cur_iter - self.last_overflow_iter) % self.window == 0:
+                if not self.consecutive_hysteresis:
+                    self.cur_hysteresis = self.hysteresis
+                self.scale *= self.factor
+        self.cur_iter += 1
 
 
 def _dev(t):
@@ -128,7 +170,8 @@ class BucketedStep:
                  bucket_bytes: int = 768 << 20, accumulate_steps: int = 1,
                  max_grad_norm: Optional[float] = None, overlap: bool = True,
                  force_collectives: bool = False, direct_grads: bool = True, model=None,
-                 zero1: bool = True, average_accumulated: bool = True):
+                 zero1: bool = True, average_accumulated: bool = True,
+                 loss_scaler: Optional[DynamicLossScaler] = None):
         if model is not None:
             # fuse q|k|v / gate|up BEFORE the parameters are pinned into buckets (the lazy fusion at
             # the first forward must never re-home a bucket view: round-2 advisor finding)
@@ -156,6 +199,8 @@ class BucketedStep:
         self.grad_scale = 1.0          # multiplied into every gradient inside AdamW (set to 1 / loss_scale for
                                        # fp16 training with a scaled loss; set it before the backward)
         self.grad_norm = None          # device scalar (fp32) of the last clipped step
+        self.loss_scaler = loss_scaler # dynamic fp16 loss scale: see scale_loss() / loss_scale
+        self.last_step_skipped = False
         self._micro = 0
         self._order = None             # frozen launch order (bucket indices); None until the discovery step ran
         self._cursor = 0
@@ -271,6 +316,18 @@ class BucketedStep:
     def set_lr(self, lr: float):
         self.opt.lr = float(lr)
 
+    @property
+    def loss_scale(self) -> float:
+        """what the loss has to be multiplied by before backward() (1 without a scaler)"""
+        return self.loss_scaler.scale if self.loss_scaler is not None else 1.0
+
+    def scale_loss(self, loss):
+        return loss * self.loss_scale if self.loss_scaler is not None else loss
+
+    def _needs_global(self) -> bool:
+        """the updates wait for a statistic of ALL gradients (clip factor / overflow verdict)"""
+        return self.max_grad_norm is not None or self.loss_scaler is not None
+
     def begin(self):
         """call before the backward of every micro-batch"""
         first = self._micro == 0
@@ -328,7 +385,7 @@ class BucketedStep:
 
     def _acc_scale(self) -> float:
         acc = 1.0 / self.accumulate_steps if (self.average_accumulated and self.accumulate_steps > 1) else 1.0
-        return acc * float(self.grad_scale)
+        return acc * float(self.grad_scale) / self.loss_scale
 
     def _launch(self, b: _Bucket):
         b.launched = True
@@ -340,7 +397,7 @@ class BucketedStep:
         else:
             h = dist.all_reduce(b.g, op=op, group=self.group, async_op=self.overlap)
         b.rs = (h, False)
-        if self.max_grad_norm is None and self.side is not None:
+        if not self._needs_global() and self.side is not None:
             (b.shard_g if self.zero1 else b.g).record_stream(self.side)
             with torch.cuda.stream(self.side):
                 self._finish_bucket(b, self._acc_scale())
@@ -423,17 +480,26 @@ class BucketedStep:
             self._zero_missing(b)
             self._launch(b)
             self._cursor += 1
-        queued = self.collective and self.max_grad_norm is None and self.side is not None
+        queued = self.collective and not self._needs_global() and self.side is not None
+        self.last_step_skipped = False
         if not queued:
             scale = self._acc_scale()
-            if self.max_grad_norm is not None:
+            if self._needs_global():
                 scale = self._clip_scale(scale)
-            if not self.collective and hasattr(self.opt, "step_buckets") and self.buckets[0].w.is_cuda:
+            if scale is None:                  # non-finite gradients under a dynamic loss scale: no update on any rank
+                self.last_step_skipped = True
+                self.opt.step_count -= 1       # (begin() counted this attempt; Adam's bias correction must not)
+                for b in self.buckets:
+                    if b.rs is not None and b.rs[0] is not None:
+                        b.rs[0].wait()
+            elif not self.collective and hasattr(self.opt, "step_buckets") and self.buckets[0].w.is_cuda:
                 self.opt.step_buckets([((b.idx, 0, b.n), b.w, b.g) for b in self.buckets], scale,
                                       dev_hyper=self.dev_hyper)
             else:
                 for i in self._order:
                     self._finish_bucket(self.buckets[i], scale)
+            if self.loss_scaler is not None:
+                self.loss_scaler.update(self.last_step_skipped)
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
         for h in self._gathers:                 # the next forward reads the gathered parameters
@@ -442,7 +508,9 @@ class BucketedStep:
         ops.bump_weight_version()               # cached fp8 copies of the weights are stale now
 
     def _clip_scale(self, acc_scale: float):
-        """grad_scale = acc_scale * min(1, max_norm / (||g|| + 1e-6)) as torch.nn.utils.clip_grad_norm_;
+        """the global statistic of a step: with `max_grad_norm`,
+        grad_scale = acc_scale * min(1, max_norm / (||g|| + 1e-6)) as torch.nn.utils.clip_grad_norm_; with a
+        dynamic loss scaler, None when ||g|| is not finite (DeepSpeed's has_overflow: the step is skipped);
         ||g|| over the rank-mean (and micro-batch-mean) gradient = acc_scale * sqrt(sum over ranks of
         the owned shards' norms^2)"""
         dev = self.params[0].device
@@ -456,9 +524,14 @@ class BucketedStep:
         if self.collective and self.zero1:
             dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
         self.grad_norm = tot.sqrt() * acc_scale
-        # the clip factor is a host scalar of AdamW's launch: one small D2H sync per step, as the
-        # reference's trainers pay for their overflow / norm checks
-        return acc_scale * min(1.0, float(self.max_grad_norm) / (float(self.grad_norm) + 1e-6))
+        # the clip factor / overflow verdict is a host scalar of AdamW's launch: one small D2H sync per
+        # step, as the reference's trainers pay for their overflow / norm checks
+        norm = float(self.grad_norm)
+        if self.loss_scaler is not None and not math.isfinite(norm):
+            return None                        # identical on every rank: `tot` was all-reduced
+        if self.max_grad_norm is None:
+            return acc_scale
+        return acc_scale * min(1.0, float(self.max_grad_norm) / (norm + 1e-6))
 
     def remove(self):
         for h in self._hooks:
@@ -483,4 +556,5 @@ class BucketedStep:
                 + (f", {ncoll} collectives per step in a fixed rank-invariant order" if ncoll else "")
                 + (f", grad accumulation x{self.accumulate_steps}"
                    + (" (mean)" if self.average_accumulated else " (sum)") if self.accumulate_steps > 1 else "")
-                + (f", clip {self.max_grad_norm}" if self.max_grad_norm is not None else ""))
+                + (f", clip {self.max_grad_norm}" if self.max_grad_norm is not None else "")
+                + (f", dynamic loss scale {self.loss_scale:g}" if self.loss_scaler is not None else ""))

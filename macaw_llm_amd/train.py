@@ -30,9 +30,11 @@ class GraphedStep:
     to time individual launches); the sequence of steps stays the same."""
 
     def __init__(self, model, loss_fn, runtime: BucketedStep, grad_scale: float = 1.0):
-        if runtime.collective or runtime.max_grad_norm is not None or runtime.accumulate_steps != 1:
-            raise ValueError("GraphedStep: needs a single-rank BucketedStep without clipping / accumulation "
-                             "(collectives and the clip factor's host read cannot be captured)")
+        if (runtime.collective or runtime.max_grad_norm is not None or runtime.accumulate_steps != 1
+                or getattr(runtime, "loss_scaler", None) is not None):
+            raise ValueError("GraphedStep: needs a single-rank BucketedStep without clipping / accumulation / dynamic "
+                             "loss scale (collectives and the host reads of the clip factor / overflow verdict "
+                             "cannot be captured)")
         self.model, self.loss_fn, self.rt, self.grad_scale = model, loss_fn, runtime, grad_scale
         self.opt = runtime.opt
         self.graph = None

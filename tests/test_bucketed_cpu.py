@@ -192,3 +192,103 @@ def test_single_process_matches_plain_sgd_and_schedule():
         sch.step()
     rt.set_lr(1e-4)
     assert opt.lr == 1e-4
+
+
+# ---------------------------------------------------------------- dynamic fp16 loss scale ---
+def test_dynamic_loss_scaler_follows_deepspeed_update_rule():
+    """deepspeed/runtime/fp16/loss_scaler.py DynamicLossScaler.update_scale, restated: with hysteresis 2 the
+    FIRST overflow only uses up the hysteresis, the second halves the scale; `window` clean steps after the last
+    overflow double it and refill the hysteresis; the floor is min_scale.  Defaults = the reference's
+    configs/deepspeed_config.json:14-21."""
+    from macaw_llm_amd.bucketed import DynamicLossScaler
+    s = DynamicLossScaler()
+    assert (s.scale, s.window, s.hysteresis, s.min_scale) == (2.0 ** 16, 1000, 2, 1.0)
+    s = DynamicLossScaler(init_scale=16.0, window=3, hysteresis=2, min_scale=2.0)
+
+    def ref_update(st, overflow):          # line-by-line restatement on a plain dict
+        if overflow:
+            if st["delayed_shift"] == 1 or st["cur_hysteresis"] == 1:
+                st["cur_scale"] = max(st["cur_scale"] / 2.0, st["min_scale"])
+            else:
+                st["cur_hysteresis"] -= 1
+            st["last_overflow_iter"] = st["cur_iter"]
+        else:
+            if (st["cur_iter"] - st["last_overflow_iter"]) % st["scale_window"] == 0:
+                st["cur_hysteresis"] = st["delayed_shift"]
+                st["cur_scale"] *= 2.0
+        st["cur_iter"] += 1
+
+    st = dict(cur_scale=16.0, cur_iter=0, last_overflow_iter=-1, scale_window=3, min_scale=2.0, delayed_shift=2,
+              cur_hysteresis=2)
+    seq = [1, 1, 0, 0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 0]
+    for ov in seq:
+        s.update(bool(ov))
+        ref_update(st, bool(ov))
+        assert s.scale == st["cur_scale"] and s.cur_hysteresis == st["cur_hysteresis"], (ov, s.scale, st)
+    assert s.skipped == sum(seq) and s.scale >= 2.0
+
+
+def _scaler_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from macaw_llm_amd.bucketed import BucketedStep, DynamicLossScaler
+        ps = _make_params()
+        big, odd, small, fa, fb, unused, lonely = ps
+        ref = dict(big=big.detach().clone(), odd=odd.detach().clone(), small=small.detach().clone(),
+                   fused=torch.cat([fa.detach(), fb.detach()]).clone())
+        opt = ShardSGD()
+        sc = DynamicLossScaler(init_scale=8.0, window=2, hysteresis=2, min_scale=1.0)
+        rt = BucketedStep([big, odd, small, fb, fa, unused, lonely], opt, bucket_bytes=6000, loss_scaler=sc)
+        eg = _expected_grads(world, 1)
+        ok = True
+        # step:      0      1         2         3      4      5
+        # overflow:  no     rank 1    rank 0    no     no     no      (ONE rank overflowing skips the step on ALL)
+        plan = [None, 1, 0, None, None, None]
+        want_scale = [8.0, 8.0, 8.0, 4.0, 4.0, 8.0, 8.0]     # the scale each step runs with (last: after step 5)
+        taken = 0
+        for it, bad in enumerate(plan):
+            ok = ok and rt.loss_scale == want_scale[it]
+            rt.begin()
+            loss = rt.scale_loss(_loss(ps, rank))
+            if bad is not None and bad % world == rank:
+                loss = loss * float("inf")
+            loss.backward()
+            rt.finish()
+            skipped = bad is not None
+            ok = ok and rt.last_step_skipped == skipped
+            if not skipped:
+                taken += 1
+                for k in ("big", "odd", "small", "fused"):
+                    ref[k] = ref[k] - 0.5 * eg[k]              # unscaled inside the update: plain SGD on the mean
+            got = dict(big=big.data, odd=odd.data, small=small.data, fused=torch.cat([fa.data, fb.data]))
+            for k in got:
+                if not torch.allclose(got[k], ref[k], atol=1e-5, rtol=1e-5):
+                    ok = False
+                    print("DEBUG scaler", world, rank, it, k, (got[k] - ref[k]).abs().max().item(), flush=True)
+        ok = ok and rt.loss_scale == want_scale[-1] and opt.step_count == taken == 4 and sc.skipped == 2
+        flat = torch.cat([b.w for b in rt.buckets])
+        others = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(others, flat)
+        ok = ok and all(torch.equal(o, others[0]) for o in others) and bool(torch.isfinite(flat).all())
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_dynamic_loss_scale_skips_overflowing_steps_on_every_rank(world):
+    """a non-finite gradient on ONE rank: no rank updates, Adam's step counter does not advance, the scale
+    backs off after the hysteresis and grows back after `window` clean steps; clean steps are exactly the
+    unscaled update (the scale is divided out inside the optimizer's grad_scale)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scaler_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(world)]

@@ -6,6 +6,8 @@ oracle/make_golden.py).  Tolerances:
   bf16 engine : bf16 storage of every activation => ~2^-8 relative per tensor; on this
                 2-layer micro model logits (|x| <= ~1) must be within 3e-2 abs / loss within 2e-2.
 """
+import math
+
 import pytest
 import torch
 
@@ -360,3 +362,42 @@ def test_fp16_training_step_with_static_loss_scale(dev):
         assert d.max().item() <= 2 * lr * steps + 2e-3 * p32[n].abs().max().item() + 1e-4, (n, d.max().item())
         mean_dev.append(d.mean().item())
     assert sum(mean_dev) / len(mean_dev) <= 0.5 * lr * steps, sum(mean_dev) / len(mean_dev)
+
+
+def test_fp16_training_with_the_dynamic_loss_scale_of_the_reference_recipe(dev):
+    """configs/deepspeed_config.json:14-21 (fp16: loss_scale 0 = dynamic): BucketedStep(loss_scaler=
+    DynamicLossScaler(...)).  Started far too high (2^24: the scaled loss is not representable in fp16), the
+    first steps overflow -- no update, Adam's step counter does not advance, the scale halves (hysteresis 1) --
+    until the gradients are finite; from then on every step updates and the loss falls as in the static-scale
+    test above.  The overflow verdict is the global gradient norm (mk_sumsq over the buckets)."""
+    from macaw_llm_amd.optim import FusedAdamW
+    from macaw_llm_amd.bucketed import BucketedStep, DynamicLossScaler
+    fx = load_case("micro_all")
+    cfg = configs.get(fx["config_name"])
+    inp = to_dev(fx["inputs"], dev)
+    model = build_model(cfg, fx["state"], torch.float16, dev, fuse=True).eval()
+    params = [p for p in model.parameters() if p.requires_grad]
+    before = [p.detach().clone() for p in params]
+    opt = FusedAdamW(params, lr=1e-3, weight_decay=0.0)
+    sc = DynamicLossScaler(init_scale=2.0 ** 24, window=1000, hysteresis=1)
+    rt = BucketedStep(params, opt, bucket_bytes=64 << 10, loss_scaler=sc)
+    losses, skipped = [], []
+    for it in range(20):
+        rt.begin()
+        loss = model(inputs=inp).loss
+        rt.scale_loss(loss).backward()
+        rt.finish()
+        losses.append(loss.item())
+        skipped.append(rt.last_step_skipped)
+        if it == 0:      # the very first attempt must have been rejected without touching anything
+            assert rt.last_step_skipped and opt.step_count == 0
+            assert all(torch.equal(a, b.detach()) for a, b in zip(before, params))
+    torch.cuda.synchronize()
+    rt.remove()
+    n_skip = sum(skipped)
+    assert 1 <= n_skip <= 16 and not any(skipped[n_skip:]), skipped        # a run of overflows, then clean steps only
+    assert sc.scale == 2.0 ** (24 - n_skip) and sc.skipped == n_skip
+    assert opt.step_count == 20 - n_skip >= 4
+    assert all(math.isfinite(x) for x in losses) and losses[-1] < losses[n_skip] - 0.05, losses
+    assert all(torch.isfinite(p).all() for p in params)
+
