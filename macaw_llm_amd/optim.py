@@ -14,6 +14,7 @@ class FusedAdamW:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.state = {}
+        self._pending = {}        # loaded state waiting for its (lazily created) slot: see load_state_dict
 
     @property
     def param_groups(self):
@@ -42,7 +43,45 @@ class FusedAdamW:
             ops.fill_(m, 0.0)
             ops.fill_(v, 0.0)
             st = self.state[p] = (master, m, v)
+            self._restore(p, st)
         return st
+
+    # ---- checkpoint / resume (HF Trainer saves `optimizer.state_dict()` every save_steps, train.sh:24-26) ----
+    def _key_name(self, key):
+        if isinstance(key, tuple):
+            return "shard:%d:%d:%d" % key             # (bucket, first element, elements) of bucketed.BucketedStep
+        for i, p in enumerate(self.params):
+            if p is key:
+                return "param:%d" % i
+        raise KeyError("FusedAdamW: state of a parameter that is not in self.params")
+
+    def _restore(self, key, st):
+        src = self._pending.pop(self._key_name(key), None) if self._pending else None
+        if src is not None:
+            for dst, t in zip(st, src):
+                if dst.shape != t.shape:
+                    raise ValueError(f"FusedAdamW.load_state_dict: {self._key_name(key)} has {tuple(t.shape)} elements "
+                                     f"in the checkpoint, {tuple(dst.shape)} here (different bucket layout / world size)")
+                dst.copy_(t.to(dst.device))
+
+    def state_dict(self):
+        """fp32 master weights and both moments of every slot this rank owns (under ZeRO-1: its shards only, as
+        DeepSpeed's per-rank optimizer files), the step counter and the hyper-parameters.  Tensors are the live
+        ones: clone (or torch.save) before training on."""
+        return {"step_count": self.step_count, "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps,
+                "weight_decay": self.weight_decay,
+                "state": {self._key_name(k): {"master": ma, "exp_avg": m, "exp_avg_sq": v}
+                          for k, (ma, m, v) in self.state.items()}}
+
+    def load_state_dict(self, sd):
+        """resume: slots that exist are overwritten now, the others when their first step creates them (state is
+        created lazily); the bf16 / fp16 parameters themselves come from the model's own state dict."""
+        self.step_count = int(sd["step_count"])
+        self.lr, self.betas, self.eps = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"])
+        self.weight_decay = float(sd["weight_decay"])
+        self._pending = {k: (t["master"], t["exp_avg"], t["exp_avg_sq"]) for k, t in sd["state"].items()}
+        for key, st in self.state.items():
+            self._restore(key, st)
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -262,6 +301,7 @@ class FusedAdamW:
             ops.fill_(m, 0.0)
             ops.fill_(v, 0.0)
             st = self.state[key] = (master, m, v)
+            self._restore(key, st)
         return st
 
     @torch.no_grad()

@@ -445,3 +445,51 @@ def test_bench_py_runs_its_n_gt_1_branch_with_two_ranks_on_this_gpu(dev, inject)
     else:
         assert "DEGRADED" in par and "all-reduce / replicated AdamW" in par, par
     assert d["roofline"]["launches_per_step"] > 0 and d["config"]["loss"] == d["config"]["loss"]   # not NaN
+
+
+def test_optimizer_state_dict_resumes_bit_exactly(dev):
+    """HF Trainer saves `optimizer.state_dict()` beside the model every save_steps (train.sh:24-26; the
+    reference's resume is commented out, run_clm_llms.py:556-561).  FusedAdamW.state_dict() = fp32 master
+    weights + both moments of every bucket slot + step counter; 2 steps, checkpoint, 2 more steps must equal
+    2 steps, checkpoint -> a NEW model / optimizer / runtime loaded from it -> 2 steps, bit for bit -- both when
+    the state is restored lazily (loaded before the first step) and into slots that already exist."""
+    import copy
+    from macaw_llm_amd.bucketed import BucketedStep
+    from macaw_llm_amd.optim import FusedAdamW
+    fx = load_case("micro_all")
+    cfg = configs.get(fx["config_name"])
+    inp = to_dev(fx["inputs"], dev)
+
+    def fresh():
+        model = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=True).eval()
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = FusedAdamW(params, lr=1e-3, weight_decay=0.01)
+        return model, opt, BucketedStep(params, opt, bucket_bytes=64 << 10)
+
+    def steps(model, rt, n):
+        for _ in range(n):
+            rt.begin()
+            model(inputs=inp).loss.backward()
+            rt.finish()
+        torch.cuda.synchronize()
+
+    A, opt_a, rt_a = fresh()
+    steps(A, rt_a, 2)
+    ck_model = {k: v.detach().clone() for k, v in A.state_dict().items()}
+    ck_opt = copy.deepcopy(opt_a.state_dict())
+    assert ck_opt["step_count"] == 2 and all(k.startswith("shard:") for k in ck_opt["state"])
+    assert all(t["master"].dtype == torch.float32 for t in ck_opt["state"].values())
+    steps(A, rt_a, 2)
+    want = {n: p.detach().clone() for n, p in A.named_parameters()}
+    rt_a.remove()
+    assert any(not torch.equal(want[n], ck_model[n]) for n in want if n in ck_model)      # steps 3-4 did train
+    for warm in (0, 1):
+        B, opt_b, rt_b = fresh()
+        steps(B, rt_b, warm)                       # warm = 1: the optimizer slots exist before the load
+        B.load_state_dict(ck_model)
+        opt_b.load_state_dict(ck_opt)
+        steps(B, rt_b, 2)
+        assert opt_b.step_count == 4
+        for n, p in B.named_parameters():
+            assert torch.equal(p.detach(), want[n]), (warm, n)
+        rt_b.remove()
