@@ -19,10 +19,16 @@ CSRC = PKG / "csrc"
 OBJ = PKG / "csrc" / "_obj"
 LIB = PKG / "libmacaw_hip.so"
 ARCH = "gfx950"
-SOURCES = ["gemm.hip", "gemm_v7.hip", "norm.hip", "elementwise.hip", "softmax.hip", "attention.hip",
+SOURCES = ["gemm.hip", "gemm_v7.hip", "gemm_v8.hip", "norm.hip", "elementwise.hip", "softmax.hip", "attention.hip",
            "decode.hip", "preprocess.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", *os.environ.get("MK_EXTRA_FLAGS", "").split(),
          "-Wno-unused-result"]
+
+
+# per-source flags.  gemm_v8.hip: the LDS-transposed epilogue of a 4 x 4-fragment wave tile exceeds LLVM's
+# default `#pragma unroll` size budget; left rolled, the fragment-row loop indexes the 256 accumulator
+# registers dynamically and the whole accumulator goes through scratch memory.
+FILE_FLAGS = {"gemm_v8.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
 
 
 def _hipcc() -> str:
@@ -38,13 +44,14 @@ def _digest(paths) -> str:
         h.update(p.name.encode())
         h.update(p.read_bytes())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
     srcs = [CSRC / s for s in SOURCES]
     deps = srcs + [CSRC / "common.h", CSRC / "gemm_common.h", PKG.parent / "include" / "macaw_hip.h",
-                   *sorted(CSRC.glob("*_impl.inc"))]
+                   *sorted(CSRC.glob("*.inc"))]
     stamp = OBJ / "stamp.txt"
     dig = _digest(deps)
     if not force and LIB.exists() and stamp.exists() and stamp.read_text() == dig:
@@ -54,7 +61,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     def compile_one(src: Path) -> Path:
         obj = OBJ / (src.stem + ".o")
-        cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stderr[-4000:]}")

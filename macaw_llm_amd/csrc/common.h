@@ -162,6 +162,15 @@ template <> struct E16<bf16> {
   MK_DEV static x4 tr_read(const char* lds) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds));
   }
+  // The same read for kernels that order their LDS-DMA by hand (counted vmcnt + barrier: gemm_v7 / gemm_v8).
+  // hipcc (ROCm 7.2, SIInsertWaitcnts) orders an LDS read whose memory operand has NO alias info behind EVERY
+  // outstanding LDS-DMA: it put an `s_waitcnt vmcnt(0)` in front of the first transpose read of each K-tile
+  // and drained the `buffer_load ... lds` queue those loops keep full on purpose (plain C++ LDS loads carry
+  // TBAA and never had it).  `__restrict__` gives the inlined intrinsic call !alias.scope metadata; the
+  // hand-placed wait is then the only one, so use this form ONLY behind such a wait.
+  MK_DEV static x4 tr_read_nw(const char* __restrict__ lds) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds));
+  }
 };
 template <> struct E16<_Float16> {
   typedef f16x8 x8; typedef f16x4 x4;
@@ -170,6 +179,10 @@ template <> struct E16<_Float16> {
   MK_DEV static f32x4 mma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
   MK_DEV static x4 tr_read(const char* lds) {
     // (ds_read_b64_tr_b16 moves 16-bit lanes, the element format is irrelevant to it)
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                         (__attribute__((address_space(3))) bf16x4*)(lds)));
+  }
+  MK_DEV static x4 tr_read_nw(const char* __restrict__ lds) {   // see E16<bf16>::tr_read_nw
     return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                                          (__attribute__((address_space(3))) bf16x4*)(lds)));
   }

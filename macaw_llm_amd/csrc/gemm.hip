@@ -285,6 +285,7 @@ extern "C" int mk_gemm_set_cfg(int cfg) { g_force_cfg = cfg; return MK_OK; }
 
 namespace mkg {
 int launch_v7(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st, bool fp8, bool f16);  // gemm_v7.hip
+int launch_v8(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st, bool f16);            // gemm_v8.hip
 }
 
 // y[M <= 16, N] = prologue(x) W^T (+ residual): the linear layers of one decode position per sample
@@ -419,7 +420,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
   }
   if (e16) {
     // kernel configuration: 11 = v7 256x256 quadrant-phase LDS-DMA ring (gemm_v7.hip; big aligned
-    // problems), 5 = v2 issue-lean LDS-DMA 128x128 (aligned operands, K % 64 == 0), 7 = v2 with
+    // problems), 14 = v8 256x256 with one wave per SIMD (gemm_v8.hip), 5 = v2 issue-lean LDS-DMA 128x128 (aligned operands, K % 64 == 0), 7 = v2 with
     // BK = 32 (reduction-major x reduction-major), 0 = register-staged 128x128 (anything).
     // MK_GEMM_CFG forces one where it is legal.
     static const int env_cfg0 = [] {
@@ -453,8 +454,9 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     if (env_cfg >= 0) cfg = env_cfg;
     else cfg = pick_cfg(d, nbatch, v7_ok, n_cus);
     if (fp8 && cfg != 11) cfg = 5;        // fp8 exists on the two LDS-DMA tile kernels only
-    if (cfg == 11 && !v7_ok) cfg = 5;
-    if (cfg != 0 && cfg != 5 && cfg != 7 && cfg != 11) cfg = 5;
+    if ((cfg == 11 || cfg == 14) && !v7_ok) cfg = 5;
+    if (cfg == 14 && fp8) cfg = 11;       // (v8 has no e4m3 instantiation yet)
+    if (cfg != 0 && cfg != 5 && cfg != 7 && cfg != 11 && cfg != 14) cfg = 5;
     if (cfg >= 5 && !v2_ok) cfg = 0;
     if (fp8 && cfg != 5 && cfg != 11) return MK_ERR_UNSUPPORTED;
     // Measured (profiles/): with BOTH operands reduction-major (dW = dy^T x) the global rows are
@@ -463,7 +465,8 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     if (cfg == 5 && d->a_red_major && d->b_red_major && !getenv("MK_GEMM_NO_BK32")) cfg = 7;
     const int bkv = cfg == 7 ? 32 : BK;
     mkp::set_cfg(prof, cfg);
-    const bool t256 = cfg == 11;
+    const bool v8 = cfg == 14;            // 256 x 256 tile, one wave per SIMD (gemm_v8.hip)
+    const bool t256 = cfg == 11 || v8;
     const int bm = t256 ? 256 : 128;
     const int bn = t256 ? 256 : BN;
     g.tiles_m = mk_cdiv(d->M, bm);
@@ -486,7 +489,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     // resident workgroups per CU of the chosen kernel
     const int slots = n_cus * (t256 ? 1 : (cfg == 7 ? 4 : 2));
     static const bool no_streamk = getenv("MK_GEMM_NO_STREAMK") != nullptr;
-    if (t256 && !no_streamk) {
+    if (t256 && !v8 && !no_streamk) {
       // v7: the last partial round of 256x256 tiles is computed as four 128x128 sub-tiles each
       // (one workgroup per sub-tile, full K, no partial sums) when that takes fewer rounds
       const int T = g.tiles_m * g.tiles_n, R = T % n_cus;
@@ -522,6 +525,11 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
           if (nbatch > 1) { g.lin_batch = 1; grid.z = 1; }
         }
       }
+    }
+    if (v8) {
+      const int rc = mkg::launch_v8(g, d->a_red_major != 0, d->b_red_major != 0, grid, st, f16);
+      mkp::end(prof, st);
+      return rc;
     }
     if (t256) {
       const int rc = mkg::launch_v7(g, d->a_red_major != 0, d->b_red_major != 0, grid, st, fp8, f16);

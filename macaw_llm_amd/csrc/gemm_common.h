@@ -87,7 +87,7 @@ MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, ET* C,
     if (g.scale_b) alpha *= g.scale_b[0];
   }
   __syncthreads();                  // every wave is done with the operand tiles in LDS
-  float* buf = reinterpret_cast<float*>(smem) + w * 2048;
+  float* buf = reinterpret_cast<float*>(smem) + w * (FN > 2 ? 1024 * FN : 2048);   // 32 rows x FN * 32 fp32 per wave
   const int srow = l & 31, sh = l >> 5;          // staging: this lane's accumulator row / half
   const int c4 = l % W4, rsub = l / W4;          // read-back: float4 column and row inside a pass
   const int ncol = n0 + wn0 + c4 * 4;            // first of this lane's 4 output columns

@@ -2,13 +2,17 @@
 // kernel on sampled rows + timing of mk_gemm per (shape, layout, kernel configuration).
 //
 //   hipcc -O2 --offload-arch=gfx950 scripts/gemm_bench.cpp -o scripts/probe/_probe_gemm_bench \
-//         -Lmacaw_llm_amd -lmacaw_hip -Wl,-rpath,'$ORIGIN/../../macaw_llm_amd'
+//         -Lmacaw_llm_amd -lmacaw_hip -lhipblaslt -Wl,-rpath,'$ORIGIN/../../macaw_llm_amd'
 //   scripts/probe/_probe_gemm_bench [shapes-file] > gpurun_out/gemm_bench.csv
 //
 // shapes file: one "M N K layout cfgs..." per line (layout 0 = NT fwd, 1 = NN grad-input,
 // 3 = TT grad-weight, as mk_prof_report prints them); default = the LLaMA-7B shapes of BASELINE
 // cfg 3.  Data: A ~ N(0,1), B ~ 0.02 N(0,1) (weights) like the training step, never zeros
 // (cdna_hip_programming.md rule 25).
+//
+// cfg 100 is NOT a configuration of mk_gemm: it runs the vendor library (hipBLASLt, heuristic algorithm) on the
+// same operands in the same process -- a YARDSTICK for "what this box reaches on this data" (rule 10: ceilings
+// come from a known-good reference on the same hardware).  The product never links or calls it.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -18,6 +22,7 @@
 #include <string>
 #include <vector>
 #include "../include/macaw_hip.h"
+#include <hipblaslt/hipblaslt.h>
 
 #define CK(x)                                                                     \
   do {                                                                            \
@@ -77,6 +82,42 @@ __global__ void cmp_rows(const bf16* C, long ldc, const float* ref, const int* r
   }
 }
 
+
+// ---- vendor yardstick (cfg 100): C[M][N] row-major = op(A) op(B)^T  <=>  column-major C^T (N x M) = B_op A_op
+struct LtPlan {
+  hipblasLtMatmulDesc_t md{}; hipblasLtMatrixLayout_t la{}, lb{}, lc{}; hipblasLtMatmulHeuristicResult_t res{};
+  bool ok = false;
+};
+#define LT(x) do { hipblasStatus_t s_ = (x); if (s_ != HIPBLAS_STATUS_SUCCESS) { fprintf(stderr, "%s:%d hipblaslt status %d\n", __FILE__, __LINE__, (int)s_); return p; } } while (0)
+static LtPlan lt_plan(hipblasLtHandle_t h, int M, int N, int K, long lda, long ldb, long ldc, int a_red, int b_red,
+                      size_t ws_bytes) {
+  LtPlan p;
+  LT(hipblasLtMatmulDescCreate(&p.md, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+  // first operand = our B: stored [N][K] (column-major K x N, op T) or, reduction-major, [K][N] (N x K, op N)
+  const int32_t opa = b_red ? HIPBLAS_OP_N : HIPBLAS_OP_T;
+  // second operand = our A: stored [M][K] (column-major K x M, op N) or [K][M] (M x K, op T)
+  const int32_t opb = a_red ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+  LT(hipblasLtMatmulDescSetAttribute(p.md, HIPBLASLT_MATMUL_DESC_TRANSA, &opa, sizeof opa));
+  LT(hipblasLtMatmulDescSetAttribute(p.md, HIPBLASLT_MATMUL_DESC_TRANSB, &opb, sizeof opb));
+  LT(hipblasLtMatrixLayoutCreate(&p.la, HIP_R_16BF, b_red ? N : K, b_red ? K : N, ldb));
+  LT(hipblasLtMatrixLayoutCreate(&p.lb, HIP_R_16BF, a_red ? M : K, a_red ? K : M, lda));
+  LT(hipblasLtMatrixLayoutCreate(&p.lc, HIP_R_16BF, N, M, ldc));
+  hipblasLtMatmulPreference_t pref;
+  LT(hipblasLtMatmulPreferenceCreate(&pref));
+  uint64_t wsb = ws_bytes;
+  LT(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsb, sizeof wsb));
+  int n = 0;
+  LT(hipblasLtMatmulAlgoGetHeuristic(h, p.md, p.la, p.lb, p.lc, p.lc, pref, 1, &p.res, &n));
+  hipblasLtMatmulPreferenceDestroy(pref);
+  p.ok = n > 0;
+  return p;
+}
+static int lt_run(hipblasLtHandle_t h, const LtPlan& p, const void* A, const void* B, void* C, void* ws, size_t wsb,
+                  hipStream_t st) {
+  const float one = 1.f, zero = 0.f;
+  return (int)hipblasLtMatmul(h, p.md, &one, B, p.la, A, p.lb, &zero, C, p.lc, C, p.lc, &p.res.algo, ws, wsb, st);
+}
+
 struct Shape { int M, N, K, layout; std::vector<int> cfgs; };
 
 int main(int argc, char** argv) {
@@ -121,6 +162,7 @@ int main(int argc, char** argv) {
   CK(hipMemset(ws, 0, 4096));
   float* stats;
   CK(hipMalloc(&stats, 16));
+  hipblasLtHandle_t lth = nullptr;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -201,16 +243,25 @@ int main(int argc, char** argv) {
     d.dtype = MK_BF16;
     d.ws = ws; d.ws_bytes = WS;
     if (kpad != s.K) d.flags = (a_red ? 0 : MK_GEMM_A_KPAD_ZERO) | (b_red ? 0 : MK_GEMM_B_KPAD_ZERO);
+    LtPlan ltp;
+    for (int c : s.cfgs)
+      if (c == 100 && !ltp.ok) {
+        if (!lth && hipblasLtCreate(&lth) != HIPBLAS_STATUS_SUCCESS) { fprintf(stderr, "hipblasLtCreate failed\n"); return 4; }
+        ltp = lt_plan(lth, s.M, s.N, s.K, lda, ldb, ldc, a_red, b_red, WS);
+        if (!ltp.ok) fprintf(stderr, "hipblaslt: no algorithm for %d %d %d layout %d\n", s.M, s.N, s.K, s.layout);
+      }
     std::vector<double> best(s.cfgs.size(), 1e30);
     std::vector<float> err(s.cfgs.size() * 3, 0.f);
     for (int rd = 0; rd < rounds; ++rd) {
       for (size_t ci = 0; ci < s.cfgs.size(); ++ci) {   // interleaved A/B rounds (rule 24)
-        mk_gemm_set_cfg(s.cfgs[ci]);
+        const bool vendor = s.cfgs[ci] == 100;
+        if (vendor && !ltp.ok) { best[ci] = 0; continue; }
+        if (!vendor) mk_gemm_set_cfg(s.cfgs[ci]);
         if (rd == 0) {
           CK(hipMemsetAsync(C, 0xff, nc * 2, st));   // poison: untouched outputs show as NaN
           CK(hipMemsetAsync(stats, 0, 16, st));
-          int rc = mk_gemm(&d, st);
-          if (rc) { fprintf(stderr, "mk_gemm rc %d\n", rc); return 3; }
+          int rc = vendor ? lt_run(lth, ltp, A, B, C, ws, WS, st) : mk_gemm(&d, st);
+          if (rc) { fprintf(stderr, "%s rc %d\n", vendor ? "hipblasLtMatmul" : "mk_gemm", rc); return 3; }
           hipLaunchKernelGGL(cmp_rows, dim3((s.N + 255) / 256, rows.size()), dim3(256), 0, st, C, ldc, ref,
                              drows, (int)rows.size(), s.N, stats);
           CK(hipMemcpyAsync(&err[ci * 3], stats, 12, hipMemcpyDeviceToHost, st));
@@ -220,7 +271,8 @@ int main(int argc, char** argv) {
           mk_gemm_desc dc = d;
           dc.A = A + (long)(i % ncopy) * na;
           dc.B = B + (long)(i % ncopy) * nb;
-          mk_gemm(&dc, st);
+          if (vendor) lt_run(lth, ltp, dc.A, dc.B, C, ws, WS, st);
+          else mk_gemm(&dc, st);
         };
         for (int i = 0; i < 2; ++i) launch(i + 7);
         CK(hipEventRecord(e0, st));
@@ -233,7 +285,7 @@ int main(int argc, char** argv) {
       }
     }
     for (size_t ci = 0; ci < s.cfgs.size(); ++ci) {
-      const double tf = 2.0 * s.M * s.N * s.K / (best[ci] * 1e-3) / 1e12;
+      const double tf = best[ci] > 0 ? 2.0 * s.M * s.N * s.K / (best[ci] * 1e-3) / 1e12 : 0.0;
       printf("%d,%d,%d,%d,%d,%.4f,%.1f,%.4g,%.4g,%.0f\n", s.M, s.N, s.K, s.layout, s.cfgs[ci], best[ci], tf,
              err[ci * 3], err[ci * 3 + 1], err[ci * 3 + 2]);
       fflush(stdout);

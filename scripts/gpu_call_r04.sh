@@ -1,0 +1,43 @@
+#!/bin/bash
+# one gpurun call of round 4: everything is written under gpurun_out/r04/<tag>/
+# usage: scripts/gpu_call_r04.sh <tag> <step> [<step> ...]
+set -u
+tag=$1; shift
+out=gpurun_out/r04/$tag
+mkdir -p $out
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+GB=scripts/probe/_probe_gemm_bench
+for step in "$@"; do
+  t0=$(date +%s)
+  case $step in
+    v8)      # v7 / v8 / vendor yardstick on cubes, step shapes and edges
+      GB_ITERS=10 GB_ROUNDS=3 timeout 600 $GB scripts/gemm_shapes_v8.txt > $out/gemm_v8.csv 2> $out/gemm_v8.err
+      GB_COLD=1 GB_ITERS=10 GB_ROUNDS=2 timeout 600 $GB scripts/gemm_shapes_v8.txt > $out/gemm_v8_cold.csv 2>> $out/gemm_v8.err ;;
+    trwait)  # v7 reduction-major layouts with / without the compiler's vmcnt(0) before transpose reads
+      for i in 1 2; do
+        LD_LIBRARY_PATH=scripts/probe/_probe_trwait GB_ITERS=10 GB_ROUNDS=2 timeout 300 $GB scripts/gemm_shapes_trwait.txt > $out/trwait_compilerwait_$i.csv 2>> $out/trwait.err
+        GB_ITERS=10 GB_ROUNDS=2 timeout 300 $GB scripts/gemm_shapes_trwait.txt > $out/trwait_nowait_$i.csv 2>> $out/trwait.err
+      done ;;
+    tgemm)
+      timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fp8_gpu.py -k "gemm or fp8" -q -rf --timeout 240 -p no:cacheprovider > $out/t_gemm.log 2>&1
+      echo "pytest rc=$?" >> $out/t_gemm.log ;;
+    tests)
+      timeout 1200 python -m pytest tests -m gpu -q -rf --timeout 300 --durations=12 -p no:cacheprovider > $out/tests.log 2>&1
+      echo "pytest rc=$?" >> $out/tests.log ;;
+    bench)
+      timeout 600 python bench.py --steps 8 --warmup 3 > $out/bench_cfg3.json 2> $out/bench_cfg3.err ;;
+    benchq)
+      timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_cfg3.json 2> $out/bench_cfg3.err ;;
+    pcsamp)  # instruction-level stall evidence: stochastic PC sampling of the v7 / v8 main loops (beta feature: bounded)
+      printf '4608 12288 4096 0 11 14\n4608 4096 12288 1 11 14\n' > /tmp/pcs_shapes.txt
+      (cd /tmp && GB_ITERS=30 GB_ROUNDS=1 timeout 180 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-method stochastic \
+         --pc-sampling-unit cycles --pc-sampling-interval 65536 --kernel-trace -d /tmp/pcs -o pcs --output-format csv \
+         -- $OLDPWD/$GB /tmp/pcs_shapes.txt > $OLDPWD/$out/pcsamp.log 2>&1; echo "rc=$?" >> $OLDPWD/$out/pcsamp.log)
+      ls -la /tmp/pcs/* >> $out/pcsamp.log 2>&1
+      for f in $(find /tmp/pcs -name '*.csv' -size -40M 2>/dev/null); do cp $f $out/ 2>/dev/null; done ;;
+    *) echo "unknown step $step" ;;
+  esac
+  echo "$step: $(( $(date +%s) - t0 )) s" >> $out/timing.txt
+done
+tail -5 $out/t_*.log $out/tests*.log 2>/dev/null
+cat $out/timing.txt

@@ -55,6 +55,18 @@ def test_the_256x256_gemm_kernels_fit_two_workgroups_of_eight_waves_per_cu(ks):
         assert v.get("private_segment_fixed_size", 0) == 0, (k, v)
 
 
+def test_the_one_wave_per_simd_gemm_keeps_its_accumulators_in_registers(ks):
+    """v8: 256 accumulator registers (AGPRs) + fragments / addresses in the other half of the 512-entry file, no
+    spill and NO scratch: with LLVM's default `#pragma unroll` budget the 4 x 4-fragment epilogue stays rolled,
+    indexes the accumulators dynamically and the whole tile goes through scratch (build.FILE_FLAGS)."""
+    found = _pick(ks, "_v8_kernel<")
+    assert len(found) == 8                                  # 4 layouts x {bf16, f16}
+    for k, v in found.items():
+        assert 256 < v["vgpr_count"] <= 512, (k, v)         # (the note counts VGPRs + AGPRs of the unified file)
+        assert v.get("vgpr_spill_count", 0) == 0 and v.get("private_segment_fixed_size", 0) == 0, (k, v)
+        assert v["max_flat_workgroup_size"] == 256, (k, v)
+
+
 def test_no_hot_kernel_spills(ks):
     """one known exception: the non-causal head-dim-128 dq kernel (4 VGPRs, 20 B of scratch; not on any
     BASELINE configuration's path -- LLaMA is causal, the alignment attention has no backward through it)"""

@@ -90,6 +90,62 @@ def test_gemm_v7_256_tile_kernel(dev, dtype, a_red, b_red, M, N, K):
     assert d <= 2 ** -7 * ref.abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize("dtype", H16)
+@pytest.mark.parametrize("a_red,b_red", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(300, 520, 128), (513, 1000, 192), (1031, 776, 320), (256, 256, 64 * 7),
+                                   (2176, 1096, 1024), (512, 768, 4096)])
+def test_gemm_v8_one_wave_per_simd_kernel(dev, dtype, a_red, b_red, M, N, K):
+    """the 256x256 one-wave-per-SIMD kernel (csrc/gemm_v8.hip) forced on ragged / short-K problems:
+    edge tiles in M and N, nk = 2, 3, 5, 7, 16, 64 (prologue / steady state / penultimate / last tile
+    paths, the three-slot A ring and two-slot B ring wrapping several times), every operand layout --
+    against torch fp32 matmul on the same 16-bit inputs, and BIT-IDENTICAL to the v7 kernel (same
+    MFMA, same k order per output element)."""
+    from macaw_llm_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + 3 * N + K + 1)
+    A = _rand((K, M) if a_red else (M, K), dtype, g)
+    B = _rand((K, N) if b_red else (N, K), dtype, g, 0.1)
+    ref = (A.float().t() if a_red else A.float()) @ (B.float() if b_red else B.float().t())
+    Ad, Bd = A.to(dev), B.to(dev)
+    ldc = (N + 7) // 8 * 8
+    outs = {}
+    try:
+        for cfg in (14, 11):
+            lib.mk_gemm_set_cfg(cfg)
+            C = torch.full((M, ldc), float("nan"), dtype=dtype, device=dev)
+            ops.gemm_raw(Ad, Bd, C, M, N, K, Ad.stride(0), Bd.stride(0), ldc, a_red=a_red, b_red=b_red)
+            outs[cfg] = C
+    finally:
+        lib.mk_gemm_set_cfg(-1)
+    _close(outs[14][:, :N], ref, dtype, scale=0.1 * math.sqrt(K), what=f"v8 {M}x{N}x{K} {a_red}{b_red}")
+    assert torch.isnan(outs[14][:, N:].float()).all()      # pad columns of C untouched
+    assert torch.equal(outs[14][:, :N], outs[11][:, :N])
+
+
+def test_gemm_v8_epilogue(dev):
+    """bias + GELU + residual + accumulate through the 4 x 4-fragment LDS-transposed epilogue of v8."""
+    from macaw_llm_amd import lib as L
+    lib = L.load()
+    M, N, K = 520, 776, 256
+    g = torch.Generator().manual_seed(5)
+    A = _rand((M, K), torch.bfloat16, g).to(dev)
+    B = _rand((N, K), torch.bfloat16, g, 0.1).to(dev)
+    bias = _rand((N,), torch.bfloat16, g).to(dev)
+    R = _rand((M, N), torch.bfloat16, g).to(dev)
+    outs = {}
+    try:
+        for cfg in (14, 11):
+            lib.mk_gemm_set_cfg(cfg)
+            C = torch.ones((M, N), dtype=torch.bfloat16, device=dev)
+            ops.gemm_raw(A, B, C, M, N, K, K, K, N, bias=bias, bias_mode=1, act=1, R=R, ldr=N, accumulate=True, alpha=0.5)
+            outs[cfg] = C
+    finally:
+        lib.mk_gemm_set_cfg(-1)
+    ref = torch.nn.functional.gelu(0.5 * (A.float() @ B.float().t()) + bias.float()) + R.float() + 1.0
+    _close(outs[14], ref.cpu(), torch.bfloat16, scale=2.0, what="v8 epilogue")
+    assert torch.equal(outs[14], outs[11])
+
+
 def test_gemm_odd_rows_reduction_major_last_element(dev):
     """regression: the hardware buffer range check is per DWORD -- with an odd row count the last
     valid element of the last k-row of a reduction-major operand shares its dword with the first
