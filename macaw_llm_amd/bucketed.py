@@ -122,6 +122,16 @@ class DynamicLossScaler:
                 self.scale *= self.factor
         self.cur_iter += 1
 
+    def state_dict(self):
+        """DeepSpeed saves the loss scaler with the optimizer: scale, window position, hysteresis left"""
+        return {k: getattr(self, k) for k in ("scale", "factor", "window", "hysteresis", "min_scale",
+                                              "consecutive_hysteresis", "cur_hysteresis", "cur_iter",
+                                              "last_overflow_iter", "skipped")}
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            setattr(self, k, v)
+
 
 def _dev(t):
     return t.is_cuda
@@ -295,11 +305,22 @@ class BucketedStep:
                 self._dst[(run[0].data.data_ptr(), tot)] = bk.g[off:off + tot].view(-1, run[0].shape[1])
 
     def _install_dst(self, on: bool):
+        """the table of direct gradient destinations is process-global (the kernels' callers look a weight up by
+        address): it belongs to ONE runtime from begin() to finish()"""
         if not (self.direct_grads and self.params[0].is_cuda):
             return
+        owner = ops.GRAD_DST_OWNER[0]
+        if owner is not None and owner is not self:
+            if on:
+                raise RuntimeError("BucketedStep.begin(): another BucketedStep is between begin() and finish() "
+                                   "(two runtimes cannot share one backward window)")
+            return                                   # not ours: leave the other runtime's table alone
         ops.GRAD_DST.clear()
+        ops.GRAD_DST_TAKEN.clear()
+        ops.GRAD_DST_OWNER[0] = None
         if on:
             ops.GRAD_DST.update(self._dst)
+            ops.GRAD_DST_OWNER[0] = self
 
     def _check_homes(self):
         """every parameter must still view its bucket slot (something re-materialised it otherwise --
@@ -332,6 +353,10 @@ class BucketedStep:
         """call before the backward of every micro-batch"""
         first = self._micro == 0
         if first:
+            if hasattr(self.opt, "uniform_hyper") and not self.opt.uniform_hyper():
+                raise ValueError("BucketedStep: the optimizer's parameter groups differ in lr / betas / eps / "
+                                 "weight_decay; the bucket runtime updates every parameter with one launch "
+                                 "(build FusedAdamW with one setting, as train.sh:27-31 does)")
             self.opt.step_count += 1
             self._check_homes()
             for b in self.buckets:
@@ -506,6 +531,8 @@ class BucketedStep:
             h.wait()
         self._gathers.clear()
         ops.bump_weight_version()               # cached fp8 copies of the weights are stale now
+        if getattr(self.opt, "_loaded_keys", None) is not None and not self.last_step_skipped:
+            self.opt.assert_restored()          # every checkpoint entry found its slot (else: wrong layout)
 
     def _clip_scale(self, acc_scale: float):
         """the global statistic of a step: with `max_grad_norm`,
@@ -540,6 +567,33 @@ class BucketedStep:
         self._install_dst(False)
         for b in self.buckets:
             ops.PINNED_STORAGE.discard(b.w.untyped_storage().data_ptr())
+        ops.clear_fp8_cache()                   # e4m3 copies of weights that lived in these buckets
+
+    # ---------------------------------------------------------- checkpoint / resume ---
+    def layout(self) -> dict:
+        """what the optimizer's shard keys depend on: a checkpoint resumes only into the same layout"""
+        return {"world": self.world if self.collective else 1, "rank": self.rank if self.collective else 0,
+                "zero1": bool(self.zero1 and self.collective), "bucket_elems": [int(b.n) for b in self.buckets],
+                "dtypes": [str(b.w.dtype) for b in self.buckets]}
+
+    def state_dict(self) -> dict:
+        """optimizer shards of THIS rank (fp32 master + moments per bucket slot, step counter, hyper-parameters),
+        the bucket layout they are keyed by and the dynamic loss scaler -- what DeepSpeed writes per rank
+        (`*_optim_states.pt`).  The 16-bit parameters are the model's own state dict."""
+        return {"optimizer": self.opt.state_dict(layout=self.layout()),
+                "loss_scaler": self.loss_scaler.state_dict() if self.loss_scaler is not None else None,
+                "grad_scale": float(self.grad_scale)}
+
+    def load_state_dict(self, sd: dict):
+        """raises if the checkpoint was written with another world size / rank / bucket size (the shard keys
+        would match nothing and the moments would silently restart at zero under a restored step counter)"""
+        self.opt.load_state_dict(sd["optimizer"], layout=self.layout())
+        if sd.get("loss_scaler") is not None:
+            if self.loss_scaler is None:
+                raise ValueError("BucketedStep.load_state_dict: the checkpoint carries a dynamic loss scaler, this "
+                                 "runtime has none (pass loss_scaler=DynamicLossScaler())")
+            self.loss_scaler.load_state_dict(sd["loss_scaler"])
+        self.grad_scale = float(sd.get("grad_scale", self.grad_scale))
 
     # -------------------------------------------------------------- introspection ---
     def describe(self) -> str:

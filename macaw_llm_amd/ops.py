@@ -237,6 +237,10 @@ def linear_dx(dy, W, out=None, accumulate=False, residual=None, dy_pad_zero=Fals
 # the grad-weight GEMM stores straight into the buffer the collective reads (no copy, no per-step
 # gradient allocation).  Empty = every dW gets a fresh tensor (the default).
 GRAD_DST = {}
+GRAD_DST_OWNER = [None]     # the BucketedStep whose table is installed (begin() ... finish())
+GRAD_DST_TAKEN = set()      # keys handed out in the current backward: a direct store OVERWRITES its slot, so a
+                            # parameter whose gradient is produced twice (tied / shared weights, a module called
+                            # twice) gets the slot once and a fresh tensor afterwards (autograd sums the two)
 
 # data_ptr of every storage that a BucketedStep owns (parameter buckets).  Parameters living there
 # must never be re-homed by the lazy q|k|v / gate|up fusion of modeling.py: the optimizer and the
@@ -253,12 +257,16 @@ def grad_dst(w):
     """registered destination for the gradient of parameter `w` (same shape), else None"""
     if not GRAD_DST or w is None:
         return None
-    d = GRAD_DST.get((w.data_ptr(), w.numel()))
+    key = (w.data_ptr(), w.numel())
+    d = GRAD_DST.get(key)
+    if d is not None and key in GRAD_DST_TAKEN:
+        return None
     if d is not None and d.dtype == w.dtype and d.numel() == w.numel() and (d.shape == w.shape or w.is_contiguous()):
         # a FRESH view object every time: autograd's AccumulateGrad takes a returned gradient as p.grad
         # without copying only if nobody else references that tensor object -- handing out the
         # dictionary's own tensor made it clone every such gradient (and the hook copy it back):
         # ~150 hidden device copies + ~150 copy-backs per step in round 2's "direct" path
+        GRAD_DST_TAKEN.add(key)
         return d.view(w.shape)
     return None
 

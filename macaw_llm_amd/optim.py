@@ -8,30 +8,73 @@ import torch
 from . import ops
 
 
-class FusedAdamW:
+class _Slot(tuple):
+    """(master, exp_avg, exp_avg_sq) of one parameter / bucket shard.  A tuple for the kernels' callers, a mapping
+    for code that walks `optimizer.state` the torch way (accelerate / HF move or inspect `state.values()` items)."""
+    _NAMES = ("master", "exp_avg", "exp_avg_sq")
+
+    def items(self):
+        return zip(self._NAMES, self)
+
+    def keys(self):
+        return iter(self._NAMES)
+
+    def values(self):
+        return iter(self)
+
+    def __getitem__(self, k):
+        return tuple.__getitem__(self, self._NAMES.index(k) if isinstance(k, str) else k)
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """A `torch.optim.Optimizer`: `param_groups`, `step(closure)`, `zero_grad()`, `state_dict()` /
+    `load_state_dict()`, `add_param_group()`, LR schedulers (`torch.optim.lr_scheduler.*`, HF's
+    `get_cosine_schedule_with_warmup`) and `transformers.Trainer(optimizers=(opt, sched))` work on it.  The
+    hyper-parameters live in `param_groups` (the single source of truth: `opt.lr` etc. are views of group 0);
+    the bucket runtime (bucketed.BucketedStep) updates every parameter with ONE launch and therefore needs the
+    groups to agree on lr / betas / eps / weight_decay at step time (the reference trains with one setting:
+    train.sh:27-31 `--weight_decay 0.`); the per-parameter `step()` honours each group's own values."""
+
     def __init__(self, params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        self.params = [p for p in params if p.requires_grad]
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        params = list(params)
+        if params and isinstance(params[0], dict):
+            groups = [dict(g, params=[p for p in g["params"] if p.requires_grad]) for g in params]
+            groups = [g for g in groups if g["params"]]
+        else:
+            groups = [p for p in params if p.requires_grad]
+        if not groups:
+            raise ValueError("FusedAdamW: no trainable parameters")
+        super().__init__(groups, dict(lr=float(lr), betas=tuple(betas), eps=float(eps),
+                                      weight_decay=float(weight_decay)))
         self.step_count = 0
-        self.state = {}
         self._pending = {}        # loaded state waiting for its (lazily created) slot: see load_state_dict
+        self._loaded_keys = None  # key names of the last load_state_dict (None: nothing was loaded)
+        self._loaded_layout = None
 
+    # ---- hyper-parameters: views of param_groups[0] (schedulers write group["lr"]) --------------------------
     @property
-    def param_groups(self):
-        """torch.optim-style view for schedulers / loggers that read or set `lr`:
-        `opt.param_groups[0]["lr"] = x` works (one group; the kernels read self.lr per launch)"""
-        outer = self
+    def params(self):
+        return [p for g in self.param_groups for p in g["params"]]
 
-        class _Group(dict):
-            def __setitem__(self, k, v):
-                if k == "lr":
-                    outer.lr = float(v)
-                elif k == "weight_decay":
-                    outer.weight_decay = float(v)
-                super().__setitem__(k, v)
+    def _hp(self, name):
+        return self.param_groups[0][name]
 
-        return [_Group(params=self.params, lr=self.lr, betas=self.betas, eps=self.eps,
-                       weight_decay=self.weight_decay)]
+    def _set_hp(self, name, v):
+        for g in self.param_groups:
+            g[name] = v
+
+    lr = property(lambda self: float(self._hp("lr")), lambda self, v: self._set_hp("lr", float(v)))
+    betas = property(lambda self: tuple(self._hp("betas")), lambda self, v: self._set_hp("betas", tuple(v)))
+    eps = property(lambda self: float(self._hp("eps")), lambda self, v: self._set_hp("eps", float(v)))
+    weight_decay = property(lambda self: float(self._hp("weight_decay")),
+                            lambda self, v: self._set_hp("weight_decay", float(v)))
+
+    def uniform_hyper(self) -> bool:
+        """True if every group has group 0's lr / betas / eps / weight_decay (what a one-launch update needs)"""
+        g0 = self.param_groups[0]
+        return all(float(g["lr"]) == float(g0["lr"]) and tuple(g["betas"]) == tuple(g0["betas"])
+                   and float(g["eps"]) == float(g0["eps"]) and float(g["weight_decay"]) == float(g0["weight_decay"])
+                   for g in self.param_groups[1:])
 
     def _state(self, p):
         st = self.state.get(p)
@@ -42,7 +85,7 @@ class FusedAdamW:
             v = torch.empty_like(master)
             ops.fill_(m, 0.0)
             ops.fill_(v, 0.0)
-            st = self.state[p] = (master, m, v)
+            st = self.state[p] = _Slot((master, m, v))
             self._restore(p, st)
         return st
 
@@ -56,36 +99,80 @@ class FusedAdamW:
         raise KeyError("FusedAdamW: state of a parameter that is not in self.params")
 
     def _restore(self, key, st):
-        src = self._pending.pop(self._key_name(key), None) if self._pending else None
-        if src is not None:
-            for dst, t in zip(st, src):
-                if dst.shape != t.shape:
-                    raise ValueError(f"FusedAdamW.load_state_dict: {self._key_name(key)} has {tuple(t.shape)} elements "
-                                     f"in the checkpoint, {tuple(dst.shape)} here (different bucket layout / world size)")
-                dst.copy_(t.to(dst.device))
+        if self._loaded_keys is None:
+            return
+        name = self._key_name(key)
+        src = self._pending.pop(name, None)
+        if src is None:
+            if name in self._loaded_keys:
+                return                                # restored before (the slot was re-created)
+            raise KeyError(f"FusedAdamW: optimizer slot {name} has no entry in the loaded checkpoint: it was saved "
+                           f"with a different bucket layout / world size / rank ({self._loaded_layout}); a silent "
+                           "restart of the moments with the restored step counter would mis-scale the first updates")
+        for dst, t in zip(st, src):
+            if dst.shape != t.shape:
+                raise ValueError(f"FusedAdamW.load_state_dict: {name} has {tuple(t.shape)} elements "
+                                 f"in the checkpoint, {tuple(dst.shape)} here (different bucket layout / world size)")
+            dst.copy_(t.to(dst.device))
 
-    def state_dict(self):
+    def assert_restored(self):
+        """after the first completed step that follows load_state_dict(): every checkpoint entry must have found
+        its slot (leftovers = entries keyed by another world size / rank / bucket size, which would otherwise be
+        dropped silently)"""
+        if self._pending:
+            left = sorted(self._pending)
+            self._pending = {}
+            raise RuntimeError(f"FusedAdamW.load_state_dict: {len(left)} checkpoint entries matched no optimizer slot "
+                               f"(first: {left[:3]}; saved layout {self._loaded_layout}): the checkpoint belongs to a "
+                               "different world size / rank / bucket layout")
+
+    def state_dict(self, layout=None):
         """fp32 master weights and both moments of every slot this rank owns (under ZeRO-1: its shards only, as
-        DeepSpeed's per-rank optimizer files), the step counter and the hyper-parameters.  Tensors are the live
-        ones: clone (or torch.save) before training on."""
+        DeepSpeed's per-rank optimizer files), the step counter, the hyper-parameters of every group and -- from
+        the bucket runtime -- the LAYOUT the shard keys depend on (world, rank, elements per bucket).  Tensors are
+        the live ones: clone (or torch.save) before training on."""
         return {"step_count": self.step_count, "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps,
                 "weight_decay": self.weight_decay,
-                "state": {self._key_name(k): {"master": ma, "exp_avg": m, "exp_avg_sq": v}
-                          for k, (ma, m, v) in self.state.items()}}
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} | {"params": len(g["params"])}
+                                 for g in self.param_groups],
+                "layout": layout,
+                "state": {self._key_name(k): {"master": st[0], "exp_avg": st[1], "exp_avg_sq": st[2]}
+                          for k, st in self.state.items()}}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, layout=None):
         """resume: slots that exist are overwritten now, the others when their first step creates them (state is
-        created lazily); the bf16 / fp16 parameters themselves come from the model's own state dict."""
+        created lazily); the bf16 / fp16 parameters themselves come from the model's own state dict.  A slot
+        created later that finds no entry raises, and so do entries nobody claimed (assert_restored(), called by
+        the bucket runtime after the first step): shard keys depend on world size, rank and bucket size.
+        `layout`: the current runtime's layout, compared with the saved one up front."""
+        saved = sd.get("layout")
+        if layout is not None and saved is not None and saved != layout:
+            raise ValueError(f"FusedAdamW.load_state_dict: the checkpoint was written with layout {saved}, this "
+                             f"runtime has {layout} (ZeRO-1 shards are per world size / rank / bucket size; re-shard "
+                             "offline or resume with the saved configuration)")
+        names = set(sd["state"])
+        for k in names:
+            if k.startswith("param:") and int(k.split(":")[1]) >= len(self.params):
+                raise ValueError(f"FusedAdamW.load_state_dict: entry {k} but only {len(self.params)} parameters")
         self.step_count = int(sd["step_count"])
-        self.lr, self.betas, self.eps = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"])
-        self.weight_decay = float(sd["weight_decay"])
+        groups = sd.get("param_groups")
+        if groups is not None and len(groups) == len(self.param_groups):
+            for g, sg in zip(self.param_groups, groups):
+                if sg.get("params") != len(g["params"]):
+                    raise ValueError("FusedAdamW.load_state_dict: parameter groups differ from the checkpoint's")
+                g.update({k: (tuple(v) if k == "betas" else v) for k, v in sg.items() if k != "params"})
+        else:
+            self.lr, self.betas, self.eps = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"])
+            self.weight_decay = float(sd["weight_decay"])
         self._pending = {k: (t["master"], t["exp_avg"], t["exp_avg_sq"]) for k, t in sd["state"].items()}
+        self._loaded_keys = names
+        self._loaded_layout = saved
         for key, st in self.state.items():
             self._restore(key, st)
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
-            p.grad = None
+            p.grad = None                # (the gradient buckets are re-zeroed by the runtime where needed)
 
     @torch.no_grad()
     def step_param(self, p, grad_scale: float = 1.0):
@@ -300,7 +387,7 @@ class FusedAdamW:
             v = torch.empty_like(master)
             ops.fill_(m, 0.0)
             ops.fill_(v, 0.0)
-            st = self.state[key] = (master, m, v)
+            st = self.state[key] = _Slot((master, m, v))
             self._restore(key, st)
         return st
 
@@ -317,6 +404,25 @@ class FusedAdamW:
                    self.step_count, grad_scale)
 
     @torch.no_grad()
-    def step(self, grad_scale: float = 1.0):
+    def step(self, closure=None, grad_scale: float = 1.0):
+        """torch.optim.Optimizer.step: one multi-tensor launch per parameter group (each with its own lr /
+        weight_decay / betas / eps).  Under a BucketedStep runtime the update already happened in finish() and
+        the runtime's `optimizer_step_is_noop` flag makes this a no-op (hf.MacawTrainerMixin)."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if getattr(self, "_runtime_steps", False):
+            return loss
         self.step_count += 1
-        self.step_params(self.params, grad_scale)
+        if len(self.param_groups) == 1:
+            self.step_params(self.param_groups[0]["params"], grad_scale)
+        else:
+            saved = self.param_groups
+            try:
+                for g in saved:                       # the kernels read group 0's values: one group at a time
+                    self.param_groups = [g]
+                    self.step_params(g["params"], grad_scale)
+            finally:
+                self.param_groups = saved
+        return loss

@@ -36,6 +36,9 @@ class GraphedStep:
                              "loss scale (collectives and the host reads of the clip factor / overflow verdict "
                              "cannot be captured)")
         self.model, self.loss_fn, self.rt, self.grad_scale = model, loss_fn, runtime, grad_scale
+        # the eager steps (warm-up, eager_step()) take their scale from the runtime, the replays from
+        # update_hyper(): ONE value, or a replay is not the eager step it stands for
+        runtime.grad_scale = float(grad_scale)
         self.opt = runtime.opt
         self.graph = None
         self.loss = None
@@ -93,5 +96,6 @@ class GraphedStep:
             self.opt.step_count += 1
             self.opt.update_hyper(dev, self.grad_scale)
         self.graph.replay()
+        ops.bump_weight_version()      # the weights changed inside the replay: cached e4m3 copies are stale
         self._graph_steps += 1
         return self.loss

@@ -18,6 +18,12 @@ for step in "$@"; do
         LD_LIBRARY_PATH=scripts/probe/_probe_trwait GB_ITERS=10 GB_ROUNDS=2 timeout 300 $GB scripts/gemm_shapes_trwait.txt > $out/trwait_compilerwait_$i.csv 2>> $out/trwait.err
         GB_ITERS=10 GB_ROUNDS=2 timeout 300 $GB scripts/gemm_shapes_trwait.txt > $out/trwait_nowait_$i.csv 2>> $out/trwait.err
       done ;;
+    v8var)   # v8 schedule variants and timing-only ablations (scripts/probe/build_v8_variants.sh)
+      for i in 1 2; do for v in 1 0 3 4 5; do
+        LD_LIBRARY_PATH=scripts/probe/_probe_v8var MK_GEMM_V8_VAR=$v GB_ITERS=10 GB_ROUNDS=2 timeout 120 $GB scripts/gemm_shapes_v8var.txt > $out/v8var_${v}_$i.csv 2>> $out/v8var.err
+      done; done
+      printf '4096 4096 4096 0 11 100\n8192 8192 8192 0 11 100\n4608 12288 4096 0 11 100\n16384 8192 4096 0 11 100\n' > /tmp/ref_shapes.txt
+      GB_ITERS=10 GB_ROUNDS=2 timeout 120 $GB /tmp/ref_shapes.txt > $out/v8var_ref.csv 2>> $out/v8var.err ;;
     tgemm)
       timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fp8_gpu.py -k "gemm or fp8" -q -rf --timeout 240 -p no:cacheprovider > $out/t_gemm.log 2>&1
       echo "pytest rc=$?" >> $out/t_gemm.log ;;
