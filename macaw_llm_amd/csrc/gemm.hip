@@ -473,10 +473,13 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     g.tiles_n = mk_cdiv(d->N, bn);
     g.a_vec = aligned16(d->A) && (d->lda % 8 == 0) && (d->sA1 % 8 == 0) && (d->sA2 % 8 == 0);
     g.b_vec = aligned16(d->B) && (d->ldb % 8 == 0) && (d->sB1 % 8 == 0) && (d->sB2 % 8 == 0);
-    g.c_vec = ((reinterpret_cast<uintptr_t>(d->C) & 7) == 0) && (d->ldc % 4 == 0) &&
-              (d->sC1 % 4 == 0) && (d->sC2 % 4 == 0) &&
-              (!d->R || (((reinterpret_cast<uintptr_t>(d->R) & 7) == 0) && (d->ldr % 4 == 0) &&
-                         (d->sR1 % 4 == 0) && (d->sR2 % 4 == 0)));
+    const auto c_aligned = [&](uintptr_t mask, long q) {
+      return ((reinterpret_cast<uintptr_t>(d->C) & mask) == 0) && (d->ldc % q == 0) && (d->sC1 % q == 0) &&
+             (d->sC2 % q == 0) &&
+             (!d->R || (((reinterpret_cast<uintptr_t>(d->R) & mask) == 0) && (d->ldr % q == 0) &&
+                        (d->sR1 % q == 0) && (d->sR2 % q == 0)));
+    };
+    g.c_vec = c_aligned(15, 8) ? 2 : c_aligned(7, 4) ? 1 : 0;
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch);
     g.dp_tiles = g.tiles_m * g.tiles_n;
     g.lin_batch = 0;

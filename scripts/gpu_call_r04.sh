@@ -19,11 +19,28 @@ for step in "$@"; do
         GB_ITERS=10 GB_ROUNDS=2 timeout 300 $GB scripts/gemm_shapes_trwait.txt > $out/trwait_nowait_$i.csv 2>> $out/trwait.err
       done ;;
     v8var)   # v8 schedule variants and timing-only ablations (scripts/probe/build_v8_variants.sh)
-      for i in 1 2; do for v in 1 0 3 4 5; do
+      for i in 1 2; do for v in ${V8VARS:-1 0 3 4 5}; do
         LD_LIBRARY_PATH=scripts/probe/_probe_v8var MK_GEMM_V8_VAR=$v GB_ITERS=10 GB_ROUNDS=2 timeout 120 $GB scripts/gemm_shapes_v8var.txt > $out/v8var_${v}_$i.csv 2>> $out/v8var.err
       done; done
       printf '4096 4096 4096 0 11 100\n8192 8192 8192 0 11 100\n4608 12288 4096 0 11 100\n16384 8192 4096 0 11 100\n' > /tmp/ref_shapes.txt
       GB_ITERS=10 GB_ROUNDS=2 timeout 120 $GB /tmp/ref_shapes.txt > $out/v8var_ref.csv 2>> $out/v8var.err ;;
+    v8pmc)   # cycles, not seconds (DVFS): GRBM / SQ counters + kernel durations of v7, v8 variants and the vendor kernel
+      printf '8192 8192 8192 0 11 14 100\n' > /tmp/pmc_shape.txt
+      for v in ${V8VARS:-1 3}; do
+        (cd /tmp && LD_LIBRARY_PATH=$OLDPWD/scripts/probe/_probe_v8var MK_GEMM_V8_VAR=$v GB_ITERS=3 GB_ROUNDS=1 timeout 120 rocprofv3 \
+           --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
+           -d /tmp/pmcv_$v -o p --output-format csv -- $OLDPWD/$GB /tmp/pmc_shape.txt > $OLDPWD/$out/pmc_var$v.log 2>&1)
+        f=$(find /tmp/pmcv_$v -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp $f $out/pmc_var$v.csv
+        (cd /tmp && LD_LIBRARY_PATH=$OLDPWD/scripts/probe/_probe_v8var MK_GEMM_V8_VAR=$v GB_ITERS=3 GB_ROUNDS=1 timeout 120 rocprofv3 \
+           --kernel-trace -d /tmp/ktv_$v -o k --output-format csv -- $OLDPWD/$GB /tmp/pmc_shape.txt > $OLDPWD/$out/kt_var$v.log 2>&1)
+        f=$(find /tmp/ktv_$v -name '*kernel_trace.csv' | head -1); [ -n "$f" ] && cp $f $out/kt_var$v.csv
+      done ;;
+    kslope)
+      for i in 1 2; do GB_ITERS=10 GB_ROUNDS=3 timeout 200 $GB scripts/gemm_shapes_kslope.txt > $out/kslope_$i.csv 2>> $out/kslope.err; done ;;
+    kslopevar)   # the K-slope of v8 schedule variants (experiment build)
+      for v in ${V8VARS:-1 2}; do
+        LD_LIBRARY_PATH=scripts/probe/_probe_v8var MK_GEMM_V8_VAR=$v GB_ITERS=10 GB_ROUNDS=3 timeout 200 $GB scripts/gemm_shapes_kslope.txt > $out/kslope_var$v.csv 2>> $out/kslope.err
+      done ;;
     tgemm)
       timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fp8_gpu.py -k "gemm or fp8" -q -rf --timeout 240 -p no:cacheprovider > $out/t_gemm.log 2>&1
       echo "pytest rc=$?" >> $out/t_gemm.log ;;
