@@ -1,9 +1,10 @@
 // Fused (flash-style) attention forward for gfx950: softmax(scale * Q K^T + mask) V without
 // materialising the score matrix (at S = 2048 the fp32 score tensor is 537 MB per
 // sample per layer).  bf16 in/out, fp32 softmax state, head_dim 64 (CLIP / Whisper) or 128
-// (LLaMA).  Replaces modeling.py:197-215 and the HF encoder attention for the no-grad paths
-// (frozen towers, inference); the training path of the LLaMA layers keeps the GEMM + softmax
-// formulation until the fused backward lands.
+// (LLaMA).  Replaces modeling.py:197-215 and the HF encoder attention everywhere in the 16-bit engines: the
+// frozen towers, inference AND training -- the fused backward (flash_bwd_prep / _dq / _dkv in
+// attention_impl.inc) has been the LLaMA layers' training path since round 1; only the fp32 parity engine keeps
+// the GEMM + softmax formulation.
 //
 // Work decomposition: block = 4 waves, each wave owns 32 query rows; the block walks the keys
 // in tiles of 64 staged in LDS (K: [key][d] XOR-swizzled for ds_read_b128; V: [key][d] read

@@ -872,13 +872,7 @@ class MM_LLMs(PreTrainedModel):
         per (L, h) instead of by a 590k-iteration Python loop every forward."""
         key = (L, h, dtype, str(device))
         if key not in self._pe_cache:
-            i = torch.arange(0, h, 2, dtype=torch.float32)
-            div = torch.exp(-(math.log(10000.0) / h * (2 * i)))
-            posn = torch.arange(L, dtype=torch.float32)[:, None]
-            pe = torch.zeros(L, h)
-            pe[:, 0::2] = torch.sin(posn * div)
-            pe[:, 1::2] = torch.cos(posn * div)
-            self._pe_cache[key] = ops.cast(pe.to(device), dtype)
+            self._pe_cache[key] = ops.cast(create_positional_encoding(L, h).to(device), dtype)
         return self._pe_cache[key]
 
     def encode_video(self, videos):
@@ -886,16 +880,22 @@ class MM_LLMs(PreTrainedModel):
                                   "encode_video_long); not on the hot path")
 
 
-create_positional_encoding = None  # the reference's python-loop helper is not part of the product path
-
-
-def add_positional_encoding(tensor):
-    """modeling.py:1108-1118 on the device path."""
-    N, L, h = tensor.size()
+def create_positional_encoding(L, h):
+    """modeling.py:1095-1106, vectorised (the reference fills the [L, h] table with a Python double loop):
+    pe[pos, i] = sin(pos * w_i), pe[pos, i + 1] = cos(pos * w_i), w_i = exp(-(ln 10000 / h) * 2 i) for EVEN i --
+    the reference's exponent uses 2 i with i already stepping by 2, kept as it is.  fp32 on
+    the CPU like the reference's; pinned to it by tests/test_oracle.py::test_reference_positional_encoding."""
     i = torch.arange(0, h, 2, dtype=torch.float32)
     div = torch.exp(-(math.log(10000.0) / h * (2 * i)))
     posn = torch.arange(L, dtype=torch.float32)[:, None]
     pe = torch.zeros(L, h)
     pe[:, 0::2] = torch.sin(posn * div)
     pe[:, 1::2] = torch.cos(posn * div)
+    return pe
+
+
+def add_positional_encoding(tensor):
+    """modeling.py:1108-1118 on the device path."""
+    N, L, h = tensor.size()
+    pe = create_positional_encoding(L, h)
     return eng.AddBroadcastFn.apply(tensor, ops.cast(pe.to(tensor.device), tensor.dtype))

@@ -69,6 +69,18 @@ class FusedAdamW(torch.optim.Optimizer):
     weight_decay = property(lambda self: float(self._hp("weight_decay")),
                             lambda self, v: self._set_hp("weight_decay", float(v)))
 
+    def attach_runtime(self, runtime):
+        """the bucket runtime that owns the update from now on (hf.MacawTrainerMixin): `step()` becomes a no-op
+        (the update happens in runtime.finish()), `state_dict()` / `load_state_dict()` carry and check the
+        runtime's bucket layout and its dynamic loss scaler"""
+        import weakref
+        self._runtime_steps = True
+        self._runtime_ref = weakref.ref(runtime)
+
+    def _runtime(self):
+        ref = getattr(self, "_runtime_ref", None)
+        return ref() if ref is not None else None
+
     def uniform_hyper(self) -> bool:
         """True if every group has group 0's lr / betas / eps / weight_decay (what a one-launch update needs)"""
         g0 = self.param_groups[0]
@@ -131,8 +143,12 @@ class FusedAdamW(torch.optim.Optimizer):
         DeepSpeed's per-rank optimizer files), the step counter, the hyper-parameters of every group and -- from
         the bucket runtime -- the LAYOUT the shard keys depend on (world, rank, elements per bucket).  Tensors are
         the live ones: clone (or torch.save) before training on."""
+        rt = self._runtime()
+        if layout is None and rt is not None:
+            layout = rt.layout()
+        scaler = rt.loss_scaler.state_dict() if (rt is not None and rt.loss_scaler is not None) else None
         return {"step_count": self.step_count, "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps,
-                "weight_decay": self.weight_decay,
+                "weight_decay": self.weight_decay, "loss_scaler": scaler,
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} | {"params": len(g["params"])}
                                  for g in self.param_groups],
                 "layout": layout,
@@ -146,6 +162,11 @@ class FusedAdamW(torch.optim.Optimizer):
         the bucket runtime after the first step): shard keys depend on world size, rank and bucket size.
         `layout`: the current runtime's layout, compared with the saved one up front."""
         saved = sd.get("layout")
+        rt = self._runtime()
+        if layout is None and rt is not None:
+            layout = rt.layout()
+        if rt is not None and rt.loss_scaler is not None and sd.get("loss_scaler") is not None:
+            rt.loss_scaler.load_state_dict(sd["loss_scaler"])
         if layout is not None and saved is not None and saved != layout:
             raise ValueError(f"FusedAdamW.load_state_dict: the checkpoint was written with layout {saved}, this "
                              f"runtime has {layout} (ZeRO-1 shards are per world size / rank / bucket size; re-shard "
@@ -165,7 +186,9 @@ class FusedAdamW(torch.optim.Optimizer):
             self.lr, self.betas, self.eps = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"])
             self.weight_decay = float(sd["weight_decay"])
         self._pending = {k: (t["master"], t["exp_avg"], t["exp_avg_sq"]) for k, t in sd["state"].items()}
-        self._loaded_keys = names
+        # (an EMPTY state at step 0 is not a checkpoint: accelerate round-trips a fresh optimizer's state_dict
+        # through load_state_dict when it wraps it)
+        self._loaded_keys = names if (names or self.step_count) else None
         self._loaded_layout = saved
         for key, st in self.state.items():
             self._restore(key, st)

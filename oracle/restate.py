@@ -372,7 +372,7 @@ def greedy_generate(sd: SD, inputs_embeds, cfg, max_new_tokens=128, eos=2, pad=3
     B = inputs_embeds.shape[0]
     emb = inputs_embeds
     out = []
-    done = torch.zeros(B, dtype=torch.bool)
+    done = torch.zeros(B, dtype=torch.bool, device=inputs_embeds.device)
     for _ in range(max_new_tokens):
         _, logits = llama_forward(sd, "llm.", emb, None, cfg["llama"])
         nxt = logits[:, -1, :].argmax(-1)

@@ -41,6 +41,9 @@ for step in "$@"; do
       for v in ${V8VARS:-1 2}; do
         LD_LIBRARY_PATH=scripts/probe/_probe_v8var MK_GEMM_V8_VAR=$v GB_ITERS=10 GB_ROUNDS=3 timeout 200 $GB scripts/gemm_shapes_kslope.txt > $out/kslope_var$v.csv 2>> $out/kslope.err
       done ;;
+    tnew)    # the tests added in round 4
+      timeout 1500 python -m pytest tests/test_hf_trainer_gpu.py tests/test_train_gpu.py "tests/test_fullsize_gpu.py::test_full_llama7b_fp32_engine_within_1e_3_of_the_fp32_oracle_on_gpu" "tests/test_fullsize_gpu.py::test_generate_at_7b_dimensions_fp32_ids_bit_exact_vs_the_restated_greedy_loop" "tests/test_fullsize_gpu.py::test_full_llama7b_against_fp32_oracle_on_gpu" -q -rf -s --timeout 600 --durations=8 -p no:cacheprovider > $out/t_new.log 2>&1
+      echo "pytest rc=$?" >> $out/t_new.log ;;
     tgemm)
       timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fp8_gpu.py -k "gemm or fp8" -q -rf --timeout 240 -p no:cacheprovider > $out/t_gemm.log 2>&1
       echo "pytest rc=$?" >> $out/t_gemm.log ;;

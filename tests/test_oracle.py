@@ -137,3 +137,7 @@ def test_restatement_matches_live_reference(mods):
 def test_reference_positional_encoding():
     mod = ref_loader.load_reference_modeling()
     assert (mod.create_positional_encoding(12, 48) - restate.positional_encoding(12, 48)).abs().max().item() < 1e-6
+    # the product's exported helper (same name as the reference's: root modeling.py shim) is the vectorised form
+    from macaw_llm_amd import modeling as M
+    assert (mod.create_positional_encoding(12, 48) - M.create_positional_encoding(12, 48)).abs().max().item() < 1e-6
+    assert M.create_positional_encoding(5, 8).shape == (5, 8)
