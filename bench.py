@@ -279,6 +279,7 @@ def main():
     dev = torch.device("cuda", dev_index)
     force_coll = bool(os.environ.get("MACAW_FORCE_COLLECTIVES"))   # 1-rank RCCL group: call-path check
     if world > 1 or force_coll:
+        os.environ.setdefault("TORCH_NCCL_ENABLE_TIMING", "1")     # per-collective device time for `comm` (below)
         kw = dict(device_id=dev) if backend == "nccl" else {}
         if force_coll and world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -399,9 +400,12 @@ def main():
         last = i == args.steps - 1
         if last:
             ops.prof_begin()
+            runtime.profile_comm(True)
         loss = step(eager=last)
     fence()
     dt = time.perf_counter() - t0
+    comm = runtime.comm_report()
+    runtime.profile_comm(False)
     if os.environ.get("MACAW_GEMM_REPORT") and rank == 0:
         ops.prof_report(os.environ["MACAW_GEMM_REPORT"])
     att_f, att_b, gemm8 = ops.prof_sum(1), ops.prof_sum(2), ops.prof_sum(3)
@@ -479,6 +483,9 @@ def main():
                          # lower triangle), same live HIP-event timing
                          "attention_fwd": rate(att_f), "attention_bwd": rate(att_b)},
         }
+        # how the step's communication went on rank 0 (last timed step): the un-overlapped tail behind the backward
+        # and every bucket's reduce-scatter / all-gather duration and bytes -- see BucketedStep.comm_report()
+        line["comm"] = comm
         if args.layers is not None:
             line["invalid"] = f"debug run with --layers {args.layers}"
         if share_gpu or backend != "nccl" or inject is not None:

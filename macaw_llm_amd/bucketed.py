@@ -220,6 +220,7 @@ class BucketedStep:
                      if (dev.type == "cuda" and overlap and self.collective) else None)
         self._build(bucket_bytes)
         self._gathers = []
+        self._comm = None              # communication profile of the step in flight (profile_comm())
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     # ------------------------------------------------------------------ layout ---
@@ -422,6 +423,8 @@ class BucketedStep:
         else:
             h = dist.all_reduce(b.g, op=op, group=self.group, async_op=self.overlap)
         b.rs = (h, False)
+        if self._comm is not None:
+            self._comm["rs"].append((b.idx, h, b.g.numel() * b.g.element_size()))
         if not self._needs_global() and self.side is not None:
             (b.shard_g if self.zero1 else b.g).record_stream(self.side)
             with torch.cuda.stream(self.side):
@@ -455,6 +458,8 @@ class BucketedStep:
             h = dist.all_gather_into_tensor(b.w, b.w[lo:lo + n], group=self.group, async_op=self.overlap)
             if h is not None:
                 self._gathers.append(h)
+            if self._comm is not None:
+                self._comm["ag"].append((b.idx, h, b.w.numel() * b.w.element_size()))
 
     def _zero_missing(self, b: _Bucket):
         """gradient slots of parameters that got no gradient in this window must read as zeros; a slot
@@ -498,6 +503,9 @@ class BucketedStep:
             return
         self._micro = 0
         self._install_dst(False)
+        if self._comm is not None and self.params[0].is_cuda:
+            self._comm["ev0"] = torch.cuda.Event(enable_timing=True)
+            self._comm["ev0"].record()          # behind the last kernel of the backward on the compute stream
         if self._order is None:
             self._freeze_order()
         while self._cursor < len(self._order):
@@ -530,6 +538,9 @@ class BucketedStep:
         for h in self._gathers:                 # the next forward reads the gathered parameters
             h.wait()
         self._gathers.clear()
+        if self._comm is not None and self.params[0].is_cuda:
+            self._comm["ev1"] = torch.cuda.Event(enable_timing=True)
+            self._comm["ev1"].record()          # the step is complete on the compute stream
         ops.bump_weight_version()               # cached fp8 copies of the weights are stale now
         if getattr(self.opt, "_loaded_keys", None) is not None and not self.last_step_skipped:
             self.opt.assert_restored()          # every checkpoint entry found its slot (else: wrong layout)
@@ -596,6 +607,51 @@ class BucketedStep:
         self.grad_scale = float(sd.get("grad_scale", self.grad_scale))
 
     # -------------------------------------------------------------- introspection ---
+    def profile_comm(self, on: bool = True):
+        """arm / disarm the communication profile of the NEXT step (bench.py arms it for its last timed step;
+        read it with comm_report() after a synchronize)"""
+        self._comm = {"rs": [], "ag": [], "ev0": None, "ev1": None} if on else None
+
+    def comm_report(self) -> Optional[dict]:
+        """what the first multi-GPU run needs to be read: the un-overlapped tail of the step
+        -- compute-stream time from the end of the backward to the end of finish(): the remaining collectives, the
+        shard updates and the all-gathers that did not fit behind the backward (at N = 1 it is the fused AdamW
+        launch: compare) -- and per bucket, in launch order, the duration and the bytes of its reduce-scatter
+        (all-reduce with zero1=False) and its all-gather.  Durations are the process group's own device-side
+        timing of each collective (ProcessGroupNCCL with TORCH_NCCL_ENABLE_TIMING=1, which bench.py sets); None
+        where the backend does not time its work objects (gloo)."""
+        c = self._comm
+        if c is None:
+            return None
+
+        def dur(h):
+            try:
+                d = h._get_duration() if h is not None else None       # ms (NCCL work, timing enabled)
+                return round(float(d), 3) if d is not None else None
+            except Exception:                                          # noqa: BLE001  (backend without timing)
+                return None
+
+        tail = None
+        if c["ev0"] is not None and c["ev1"] is not None:
+            c["ev1"].synchronize()
+            tail = round(c["ev0"].elapsed_time(c["ev1"]), 3)
+        rs = [(i, dur(h), nbytes) for i, h, nbytes in c["rs"]]
+        ag = [(i, dur(h), nbytes) for i, h, nbytes in c["ag"]]
+
+        def tot(xs):
+            ds = [d for _, d, _ in xs if d is not None]
+            return round(sum(ds), 3) if ds else None
+
+        return {"world": self.world, "collective": ("reduce_scatter+all_gather" if self.zero1 else "all_reduce")
+                if self.collective else "none",
+                "buckets": len(self.buckets), "tail_after_backward_ms": tail,
+                "rs_ms": [d for _, d, _ in rs], "ag_ms": [d for _, d, _ in ag],
+                "rs_total_ms": tot(rs), "ag_total_ms": tot(ag),
+                "rs_bytes": sum(n for _, _, n in rs), "ag_bytes": sum(n for _, _, n in ag),
+                "bucket_order": [i for i, _, _ in rs],
+                "timing": "per-collective device time from the process group (TORCH_NCCL_ENABLE_TIMING)"
+                if any(d is not None for _, d, _ in rs + ag) else "collectives not timed by this backend"}
+
     def describe(self) -> str:
         nb = len(self.buckets)
         mb = sum(b.n * b.w.element_size() for b in self.buckets) / 2 ** 20

@@ -44,6 +44,14 @@ for step in "$@"; do
     tnew)    # the tests added in round 4
       timeout 1500 python -m pytest tests/test_hf_trainer_gpu.py tests/test_train_gpu.py "tests/test_fullsize_gpu.py::test_full_llama7b_fp32_engine_within_1e_3_of_the_fp32_oracle_on_gpu" "tests/test_fullsize_gpu.py::test_generate_at_7b_dimensions_fp32_ids_bit_exact_vs_the_restated_greedy_loop" "tests/test_fullsize_gpu.py::test_full_llama7b_against_fp32_oracle_on_gpu" -q -rf -s --timeout 600 --durations=8 -p no:cacheprovider > $out/t_new.log 2>&1
       echo "pytest rc=$?" >> $out/t_new.log ;;
+    thf)
+      timeout 600 python -m pytest tests/test_hf_trainer_gpu.py -q -rf --timeout 600 -p no:cacheprovider > $out/t_hf.log 2>&1
+      echo "pytest rc=$?" >> $out/t_hf.log ;;
+    rccl1)   # the collective path through a 1-rank RCCL group: bench line with `comm`, then a kernel trace of it
+      MACAW_FORCE_COLLECTIVES=1 timeout 400 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_cfg3_1rank_rccl.json 2> $out/bench_cfg3_1rank_rccl.err
+      (cd /tmp && MACAW_FORCE_COLLECTIVES=1 timeout 500 rocprofv3 --kernel-trace -d /tmp/rccl1 -o t --output-format csv -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$out/rccl1_trace.log 2>&1)
+      f=$(find /tmp/rccl1 -name '*kernel_trace.csv' | head -1)
+      [ -n "$f" ] && python scripts/trace_last_step.py "$f" > $out/cfg3_1rank_rccl_last_step.txt 2>&1 ;;
     tgemm)
       timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fp8_gpu.py -k "gemm or fp8" -q -rf --timeout 240 -p no:cacheprovider > $out/t_gemm.log 2>&1
       echo "pytest rc=$?" >> $out/t_gemm.log ;;

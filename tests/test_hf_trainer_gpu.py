@@ -73,6 +73,7 @@ def test_hf_trainer_runs_the_bucket_runtime_and_round_trips_through_save_model(d
     data = _Samples(fx["inputs"], steps * bs * accum)
 
     # ---- the reference's driver: LLMTrainer(...).train(); save_model()
+    torch.manual_seed(0)              # (parameters outside the golden state dict keep their random init: same seed below)
     model = build_model(cfg, fx["state"], torch.float32, dev, fuse=True)
     model.llm.gradient_checkpointing_enable()                     # train.sh:38 `--gradient_checkpointing` surface
     args = TrainingArguments(output_dir=str(tmp_path / "out"), per_device_train_batch_size=bs,
@@ -96,6 +97,7 @@ def test_hf_trainer_runs_the_bucket_runtime_and_round_trips_through_save_model(d
     assert logged and all(math.isfinite(h["grad_norm"]) and h["grad_norm"] > 0 for h in logged)
 
     # ---- the same three steps by hand on the same runtime pieces: bit-identical weights
+    torch.manual_seed(0)
     ref = build_model(cfg, fx["state"], torch.float32, dev, fuse=True)
     ref.llm.gradient_checkpointing_enable()
     ref.train()
