@@ -96,9 +96,16 @@ typedef struct mk_gemm_desc {
 #define MK_GEMM_B_KPAD_ZERO 2
 int mk_gemm(const mk_gemm_desc* d, void* stream);
 /* Tuning / A-B hook: force the bf16 kernel configuration of the following mk_gemm calls
- * (11 = 256x256 v7, 5 = 128x128 v2, 7 = v2 BK32, 0 = generic; -1 = automatic).  A forced
+ * (11 = 256x256 v7, 14 = 256x256 v8 with one wave per SIMD, 5 = 128x128 v2, 7 = v2 BK32, 0 = generic; -1 = automatic).  A forced
  * configuration is still replaced where it is not legal for the problem. */
 int mk_gemm_set_cfg(int cfg);
+/* How many CUs the tile kernels may plan for (0 = all of the device, the default).  The 256x256 kernels hold one
+ * workgroup per CU with all of its LDS, so a CU occupied by another resident kernel -- an RCCL channel of the
+ * gradient reduce-scatter running beside the backward (train.sh:14, configs/deepspeed_config.json:22-41) -- is
+ * lost to them: rounds of exactly 256 tiles then take two passes.  The step runtime sets this to
+ * (CUs - collective channels) while collectives overlap the backward; round sizes, the spatial tail and the
+ * kernel choice follow.  Returns the previous value. */
+int mk_gemm_set_cus(int n_cus);
 /* Optional live timing of every mk_gemm launch with HIP events on the launch stream
  * (bench.py roofline): begin, run, then end() synchronises and returns the sums. */
 int mk_prof_begin(void);

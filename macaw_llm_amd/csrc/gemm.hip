@@ -282,6 +282,8 @@ int skinny32_cfg(int N) {
 // tuning / A-B hook (scripts/gemm_bench.cpp, tests): force a kernel configuration for the
 // following mk_gemm calls of this process (-1 = automatic choice); same meaning as MK_GEMM_CFG
 extern "C" int mk_gemm_set_cfg(int cfg) { g_force_cfg = cfg; return MK_OK; }
+namespace { int g_plan_cus = 0; }
+extern "C" int mk_gemm_set_cus(int n) { const int prev = g_plan_cus; g_plan_cus = n > 0 ? n : 0; return prev; }
 
 namespace mkg {
 int launch_v7(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st, bool fp8, bool f16);  // gemm_v7.hip
@@ -444,12 +446,14 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
                        fits(d->a_red_major, d->lda, BM) && fits(d->b_red_major, d->ldb, BN);
     const bool v7_ok = v2_ok && d->K >= 128 && d->M > 128 && d->N > 128 &&
                        fits(d->a_red_major, d->lda, 256) && fits(d->b_red_major, d->ldb, 256);
-    static const int n_cus = [] {
+    static const int dev_cus = [] {
       int dev = 0, cus = 256;
       (void)hipGetDevice(&dev);
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
       return cus;
     }();
+    // (mk_gemm_set_cus: CUs held by other resident kernels -- RCCL channels -- are not planned for)
+    const int n_cus = (g_plan_cus > 0 && g_plan_cus < dev_cus) ? g_plan_cus : dev_cus;
     int cfg;
     if (env_cfg >= 0) cfg = env_cfg;
     else cfg = pick_cfg(d, nbatch, v7_ok, n_cus);

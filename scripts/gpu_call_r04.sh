@@ -52,6 +52,8 @@ for step in "$@"; do
       (cd /tmp && MACAW_FORCE_COLLECTIVES=1 timeout 500 rocprofv3 --kernel-trace -d /tmp/rccl1 -o t --output-format csv -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$out/rccl1_trace.log 2>&1)
       f=$(find /tmp/rccl1 -name '*kernel_trace.csv' | head -1)
       [ -n "$f" ] && python scripts/trace_last_step.py "$f" > $out/cfg3_1rank_rccl_last_step.txt 2>&1 ;;
+    cuhold)  # GEMMs beside a resident kernel holding 8 / 16 / 32 CUs, planned for 256 or for the free CUs
+      timeout 300 scripts/probe/_probe_cu_hold > $out/cu_hold.csv 2> $out/cu_hold.err ;;
     tgemm)
       timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fp8_gpu.py -k "gemm or fp8" -q -rf --timeout 240 -p no:cacheprovider > $out/t_gemm.log 2>&1
       echo "pytest rc=$?" >> $out/t_gemm.log ;;

@@ -120,7 +120,8 @@ def test_hf_trainer_runs_the_bucket_runtime_and_round_trips_through_save_model(d
     # ---- trainer.save_model() -> from_pretrained -> identical logits (run_clm_llms.py:563, inference script)
     tr.save_model(str(tmp_path / "saved"))
     M.AUTO_FUSE = True
-    loaded = M.MM_LLMs.from_pretrained(str(tmp_path / "saved")).to(dev).eval()
+    from macaw_llm_amd.factory import make_config
+    loaded = M.MM_LLMs.from_pretrained(str(tmp_path / "saved"), config=make_config(cfg)).to(dev).eval()   # run_clm_llms_inference.py:455
     model.eval()
     inp = to_dev(fx["inputs"], dev)
     with torch.no_grad():
