@@ -280,6 +280,10 @@ def main():
     force_coll = bool(os.environ.get("MACAW_FORCE_COLLECTIVES"))   # 1-rank RCCL group: call-path check
     if world > 1 or force_coll:
         os.environ.setdefault("TORCH_NCCL_ENABLE_TIMING", "1")     # per-collective device time for `comm` (below)
+        # each RCCL channel is a resident workgroup that holds a CU for the whole collective; the 256 x 256 GEMM
+        # needs whole CUs (scripts/probe/cu_hold.cpp, profiles/r04_cu_hold.csv): cap the channels and let the
+        # GEMMs plan for the CUs that remain (BucketedStep(comm_cus=...)).  16 channels over 7 xGMI links.
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
         kw = dict(device_id=dev) if backend == "nccl" else {}
         if force_coll and world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -318,6 +322,8 @@ def main():
         o = FusedAdamW(params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
         return BucketedStep(params, o, model=model, overlap=not os.environ.get("MACAW_NO_OVERLAP"),
                             force_collectives=force_coll, zero1=zero1,
+                            comm_cus=int(os.environ.get("MACAW_COMM_CUS", os.environ.get("NCCL_MAX_NCHANNELS", "0")))
+                            if world > 1 else 0,
                             bucket_bytes=int(os.environ.get("MACAW_BUCKET_MB", "768")) << 20)
 
     runtime = make_runtime()

@@ -181,7 +181,7 @@ class BucketedStep:
                  max_grad_norm: Optional[float] = None, overlap: bool = True,
                  force_collectives: bool = False, direct_grads: bool = True, model=None,
                  zero1: bool = True, average_accumulated: bool = True,
-                 loss_scaler: Optional[DynamicLossScaler] = None):
+                 loss_scaler: Optional[DynamicLossScaler] = None, comm_cus: int = 0):
         if model is not None:
             # fuse q|k|v / gate|up BEFORE the parameters are pinned into buckets (the lazy fusion at
             # the first forward must never re-home a bucket view: round-2 advisor finding)
@@ -210,6 +210,12 @@ class BucketedStep:
                                        # fp16 training with a scaled loss; set it before the backward)
         self.grad_norm = None          # device scalar (fp32) of the last clipped step
         self.loss_scaler = loss_scaler # dynamic fp16 loss scale: see scale_loss() / loss_scale
+        # CUs the collective kernels hold while they overlap the backward (= RCCL channels, NCCL_MAX_NCHANNELS): the
+        # 256 x 256 GEMM needs whole CUs, so from the first collective of a step to finish() the tile kernels plan
+        # their rounds for (device CUs - comm_cus) -- scripts/probe/cu_hold.cpp: with 16 CUs held a 288-tile dx
+        # GEMM runs at 1039 TFLOP/s planned for 256 CUs, 1196 planned for 240 (1270 alone)
+        self.comm_cus = int(comm_cus) if (self.collective and overlap) else 0
+        self._cus_reserved = False
         self.last_step_skipped = False
         self._micro = 0
         self._order = None             # frozen launch order (bucket indices); None until the discovery step ran
@@ -413,10 +419,19 @@ class BucketedStep:
         acc = 1.0 / self.accumulate_steps if (self.average_accumulated and self.accumulate_steps > 1) else 1.0
         return acc * float(self.grad_scale) / self.loss_scale
 
+    def _reserve_cus(self, on: bool):
+        if not (self.comm_cus > 0 and self.params[0].is_cuda) or on == self._cus_reserved:
+            return
+        from . import lib as _L
+        total = torch.cuda.get_device_properties(self.params[0].device).multi_processor_count
+        _L.load().mk_gemm_set_cus(max(8, total - self.comm_cus) if on else 0)
+        self._cus_reserved = on
+
     def _launch(self, b: _Bucket):
         b.launched = True
         if not self.collective:
             return
+        self._reserve_cus(True)
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         if self.zero1:
             h = dist.reduce_scatter_tensor(b.shard_g, b.g, op=op, group=self.group, async_op=self.overlap)
@@ -538,6 +553,7 @@ class BucketedStep:
         for h in self._gathers:                 # the next forward reads the gathered parameters
             h.wait()
         self._gathers.clear()
+        self._reserve_cus(False)                # the forward has the whole chip again
         if self._comm is not None and self.params[0].is_cuda:
             self._comm["ev1"] = torch.cuda.Event(enable_timing=True)
             self._comm["ev1"].record()          # the step is complete on the compute stream
@@ -667,4 +683,5 @@ class BucketedStep:
                 + (f", grad accumulation x{self.accumulate_steps}"
                    + (" (mean)" if self.average_accumulated else " (sum)") if self.accumulate_steps > 1 else "")
                 + (f", clip {self.max_grad_norm}" if self.max_grad_norm is not None else "")
-                + (f", dynamic loss scale {self.loss_scale:g}" if self.loss_scaler is not None else ""))
+                + (f", dynamic loss scale {self.loss_scale:g}" if self.loss_scaler is not None else "")
+                + (f", GEMMs plan for {self.comm_cus} fewer CUs while collectives are in flight" if self.comm_cus else ""))

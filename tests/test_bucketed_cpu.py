@@ -194,6 +194,53 @@ def test_single_process_matches_plain_sgd_and_schedule():
     assert opt.lr == 1e-4
 
 
+def test_comm_report_contract_single_rank_gloo_group():
+    """bench.py's `comm` object = BucketedStep.comm_report(): armed for one step it lists every
+    bucket's reduce-scatter and all-gather in launch order with their bytes; durations are None on a backend that
+    does not time its work objects (gloo), the device-side tail only exists on a GPU."""
+    import socket
+    import torch.distributed as dist
+    from macaw_llm_amd.bucketed import BucketedStep
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        ps = _make_params()
+        rt = BucketedStep(list(ps), ShardSGD(), bucket_bytes=6000, force_collectives=True)
+        assert rt.collective and rt.comm_report() is None          # not armed
+        for armed in (False, True):                                # (the first step freezes the bucket order)
+            rt.profile_comm(armed)
+            rt.begin()
+            _loss(ps, 0).backward()
+            rt.finish()
+        rep = rt.comm_report()
+        nb = len(rt.buckets)
+        assert rep["world"] == 1 and rep["collective"] == "reduce_scatter+all_gather" and rep["buckets"] == nb
+        assert len(rep["rs_ms"]) == nb and len(rep["ag_ms"]) == nb and sorted(rep["bucket_order"]) == list(range(nb))
+        total = sum(b.g.numel() * b.g.element_size() for b in rt.buckets)
+        assert rep["rs_bytes"] == total and rep["ag_bytes"] == total
+        assert rep["tail_after_backward_ms"] is None and rep["rs_total_ms"] is None      # CPU tensors, gloo
+        assert "not timed" in rep["timing"]
+        rt.profile_comm(False)
+        assert rt.comm_report() is None
+        rt.remove()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_committed_collective_path_line_carries_comm():
+    """profiles/r04_bench_cfg3_1rank_rccl.json: the bench line of the collective path through a 1-rank RCCL group
+    on the GPU -- per-bucket device-side durations from the process group, the un-overlapped tail"""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.loads(open(os.path.join(root, "profiles", "r04_bench_cfg3_1rank_rccl.json")).read().strip().splitlines()[-1])
+    c = d["comm"]
+    assert c["collective"] == "reduce_scatter+all_gather" and c["buckets"] == len(c["rs_ms"]) == len(c["ag_ms"]) > 10
+    assert all(x is not None and x > 0 for x in c["rs_ms"]) and c["rs_total_ms"] > 0
+    assert c["rs_bytes"] == c["ag_bytes"] > 13e9                   # 6.7e9 trainable bf16 parameters + padding
+    assert 0 < c["tail_after_backward_ms"] < d["ms_per_step"]
+
+
 # ---------------------------------------------------------------- dynamic fp16 loss scale ---
 def test_dynamic_loss_scaler_follows_deepspeed_update_rule():
     """deepspeed/runtime/fp16/loss_scaler.py DynamicLossScaler.update_scale, restated: with hysteresis 2 the
