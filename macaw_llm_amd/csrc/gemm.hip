@@ -323,10 +323,14 @@ extern "C" int mk_decode_linear(const void* x, int64_t ldx, const void* W, int64
 }
 namespace {
 // Default kernel choice: a small cost model fitted to scripts/gemm_bench.cpp measurements on
-// MI355X (profiles/r02_gemm_shapes.csv; microseconds).  v7: one 256x256 tile per CU and round,
+// MI355X (microseconds; round 4 re-fit on COLD operands -- as inside a training step -- from
+// profiles/r04_gemm_enc_cold.csv, r04_gemm_kslope.csv).  v7: one 256x256 tile per CU and round,
 // (K-tiles x a7 + prologue/epilogue) per round, the last partial round as 128x128 sub-tiles when
 // that is at most two sub-rounds.  v2: 128x128 tiles, two workgroups per CU (four with BK = 32 for
-// reduction-major x reduction-major), fractional rounds through its K-split tail.
+// reduction-major x reduction-major), fractional rounds through its K-split tail.  The round-2 fit
+// priced a v2 K-tile at 0.92 us (cache-warm operands); cold it is 1.67, and with it every encoder
+// shape (K = 512 ... 1024: 8224 x 1024 x 1024 at 485 TFLOP/s on v2, 618 on v7; 8224 x 4096 x 1024
+// 641 vs 924; 48000 x 2048 x 512 683 vs 835) was on the wrong kernel.
 int pick_cfg(const mk_gemm_desc* d, int nbatch, bool v7_ok, int n_cus) {
   static const bool no_v7 = getenv("MK_GEMM_NO_V7") != nullptr;
   if (!v7_ok || no_v7 || nbatch != 1) return MK_GEMM_DEFAULT_CFG;
@@ -334,15 +338,15 @@ int pick_cfg(const mk_gemm_desc* d, int nbatch, bool v7_ok, int n_cus) {
   const double nk = (d->K + 63) / 64;
   const long T7 = (long)mk_cdiv(d->M, 256) * mk_cdiv(d->N, 256);
   const long full = T7 / n_cus, R = T7 % n_cus;
-  const double a7 = layout == 3 ? 1.63 : layout == 1 ? 1.53 : layout == 2 ? 1.57 : 1.49;
-  const double tile7 = nk * a7 + 14.0, sub7 = nk * 0.48 + 7.0;
+  const double a7 = layout == 3 ? 1.53 : layout == 1 ? 1.51 : layout == 2 ? 1.52 : 1.46;
+  const double tile7 = nk * a7 + 11.5, sub7 = nk * 0.48 + 7.0;
   double t7 = full * tile7;
   // (a partially filled round of whole tiles runs faster per K-tile: less L2 / power contention)
   if (R > 0) t7 += (4 * R <= 2 * n_cus) ? (double)mk_cdiv((int)(4 * R), n_cus) * sub7
-                                         : nk * a7 * (0.55 + 0.45 * R / n_cus) + 14.0;
+                                         : nk * a7 * (0.55 + 0.45 * R / n_cus) + 11.5;
   const long T2 = (long)mk_cdiv(d->M, 128) * mk_cdiv(d->N, 128);
   const long slots2 = (long)n_cus * (layout == 3 ? 4 : 2);
-  const double tile2 = layout == 3 ? nk * 1.77 + 8.0 : nk * (layout == 0 ? 0.92 : 1.03) + 5.0;
+  const double tile2 = layout == 3 ? nk * 2.18 + 4.0 : nk * (layout == 0 ? 1.67 : 1.45) + 2.0;
   double rounds2 = (double)T2 / slots2;
   if (rounds2 < 0.25) rounds2 = 0.25;
   double t2 = rounds2 * tile2;
