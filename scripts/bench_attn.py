@@ -1,6 +1,6 @@
 """Fused-attention micro-benchmark: forward and backward of the step's attention shapes through the C ABI.
     python scripts/bench_attn.py            # TFLOP/s per shape (algorithmic FLOPs: causal = lower triangle)
-MK_ATTN_DQ_SYNC=1 selects the synchronous-staging dq kernel of rounds 1-3 (A/B)."""
+MK_ATTN_DQ_ASYNC=1 selects the asynchronous-staging dq kernel (one workgroup per CU; A/B)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from macaw_llm_amd import ops

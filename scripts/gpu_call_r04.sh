@@ -58,7 +58,7 @@ for step in "$@"; do
       GB_COLD=1 GB_ITERS=10 GB_ROUNDS=3 timeout 300 $GB scripts/gemm_shapes_enc.txt > $out/gemm_enc_cold.csv 2> $out/gemm_enc.err ;;
     attn)    # attention micro-benchmark (async staging vs the synchronous dq), then the attention / model tests
       timeout 200 python scripts/bench_attn.py > $out/attn_async.txt 2>&1
-      MK_ATTN_DQ_SYNC=1 timeout 200 python scripts/bench_attn.py > $out/attn_dqsync.txt 2>&1
+      MK_ATTN_DQ_ASYNC=1 timeout 200 python scripts/bench_attn.py > $out/attn_dqasync.txt 2>&1
       timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -k "attn or attention or flash or forward_backward" -q -rf --timeout 300 -p no:cacheprovider > $out/t_attn.log 2>&1
       echo "pytest rc=$?" >> $out/t_attn.log ;;
     tgemm)

@@ -71,7 +71,7 @@ def test_no_hot_kernel_spills(ks):
     """one known exception: the non-causal head-dim-128 dq kernel (4 VGPRs, 20 B of scratch; not on any
     BASELINE configuration's path -- LLaMA is causal, the alignment attention has no backward through it)"""
     spilled = {k: v for k, v in ks.items() if v.get("vgpr_spill_count", 0)}      # (SGPR -> VGPR-lane spills cost nothing)
-    allowed = [k for k in spilled if "flash_bwd_dq" in k and "<128, false, false>" in k]     # (the synchronous-staging A/B partner)
+    allowed = [k for k in spilled if "flash_bwd_dq" in k and "<128, false, false>" in k]
     unexpected = {k: v for k, v in spilled.items() if k not in allowed}
     assert not unexpected, unexpected
 
