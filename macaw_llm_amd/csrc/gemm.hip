@@ -347,15 +347,25 @@ int pick_cfg(const mk_gemm_desc* d, int nbatch, bool v7_ok, int n_cus) {
   const long T2 = (long)mk_cdiv(d->M, 128) * mk_cdiv(d->N, 128);
   const long slots2 = (long)n_cus * (layout == 3 ? 4 : 2);
   const double tile2 = layout == 3 ? nk * 2.18 + 4.0 : nk * (layout == 0 ? 1.67 : 1.45) + 2.0;
-  double rounds2 = (double)T2 / slots2;
-  if (rounds2 < 0.25) rounds2 = 0.25;
-  double t2 = rounds2 * tile2;
-  if (const long R2 = T2 % slots2) {   // K-split tail: pieces + the last arriver reading `sp` slabs
-    double sp = (double)slots2 / R2;
-    const double nk2 = layout == 3 ? 2 * nk : nk;
+  const double a2 = layout == 3 ? 2.18 : layout == 0 ? 1.67 : 1.45;
+  const double nk2 = layout == 3 ? 2 * nk : nk;
+  double t2;
+  if (T2 < slots2) {
+    // less than one round of tiles: the K-split tail takes the WHOLE problem (project_audio: K = 122,880;
+    // the alignment P V: K = 32,064; 192 x 768 x 36,864): every tile is cut into `sp` K-pieces
+    double sp = (double)(slots2 / T2);
     if (sp > nk2 / 2) sp = nk2 / 2;
     if (sp > 64) sp = 64;
-    t2 += 4.0 + 0.65 * sp;
+    if (sp < 1) sp = 1;
+    t2 = nk / sp * a2 + 2.0 + (sp > 1 ? 4.0 + 0.65 * sp : 0.0);
+  } else {
+    t2 = (double)T2 / slots2 * tile2;
+    if (const long R2 = T2 % slots2) {   // K-split tail: pieces + the last arriver reading `sp` slabs
+      double sp = (double)slots2 / R2;
+      if (sp > nk2 / 2) sp = nk2 / 2;
+      if (sp > 64) sp = 64;
+      t2 += 4.0 + 0.65 * sp;
+    }
   }
   return t7 * 0.95 < t2 ? 11 : MK_GEMM_DEFAULT_CFG;   // (ties go to v7: the model is pessimistic for it)
 }
