@@ -61,6 +61,10 @@ for step in "$@"; do
       MK_ATTN_DQ_ASYNC=1 timeout 200 python scripts/bench_attn.py > $out/attn_dqasync.txt 2>&1
       timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -k "attn or attention or flash or forward_backward" -q -rf --timeout 300 -p no:cacheprovider > $out/t_attn.log 2>&1
       echo "pytest rc=$?" >> $out/t_attn.log ;;
+    adamw)
+      for v in 0 2 1 0 2; do MK_ADAMW_VAR=$v timeout 120 python scripts/bench_adamw_multi.py 2>&1 | grep MK_ADAMW >> $out/adamw_ab.txt; done
+      timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_train_gpu.py -k "adamw or bucketed or optimizer or graphed" -q -rf --timeout 300 -p no:cacheprovider > $out/t_adamw.log 2>&1
+      echo "pytest rc=$?" >> $out/t_adamw.log ;;
     tgemm)
       timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fp8_gpu.py -k "gemm or fp8" -q -rf --timeout 240 -p no:cacheprovider > $out/t_gemm.log 2>&1
       echo "pytest rc=$?" >> $out/t_gemm.log ;;
