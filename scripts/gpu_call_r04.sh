@@ -65,6 +65,12 @@ for step in "$@"; do
       for v in 0 2 1 0 2; do MK_ADAMW_VAR=$v timeout 120 python scripts/bench_adamw_multi.py 2>&1 | grep MK_ADAMW >> $out/adamw_ab.txt; done
       timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_train_gpu.py -k "adamw or bucketed or optimizer or graphed" -q -rf --timeout 300 -p no:cacheprovider > $out/t_adamw.log 2>&1
       echo "pytest rc=$?" >> $out/t_adamw.log ;;
+    attn2)   # XCD-grouped grids of the attention forward: non-causal (default on) and causal (A/B)
+      timeout 200 python scripts/bench_attn.py > $out/attn_grouped.txt 2>&1
+      MK_ATTN_NO_XCD_GROUP=1 timeout 200 python scripts/bench_attn.py > $out/attn_ungrouped.txt 2>&1
+      MK_ATTN_XCD_GROUP_CAUSAL=1 timeout 200 python scripts/bench_attn.py > $out/attn_grouped_causal.txt 2>&1
+      timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -k "attn or attention or flash or forward_backward" -q -rf --timeout 300 -p no:cacheprovider > $out/t_attn.log 2>&1
+      echo "pytest rc=$?" >> $out/t_attn.log ;;
     tgemm)
       timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fp8_gpu.py -k "gemm or fp8" -q -rf --timeout 240 -p no:cacheprovider > $out/t_gemm.log 2>&1
       echo "pytest rc=$?" >> $out/t_gemm.log ;;
