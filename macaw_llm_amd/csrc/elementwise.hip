@@ -29,11 +29,25 @@ __global__ __launch_bounds__(256) void rope_kernel(T* x, const T* cos_t, const T
   const int half = hd / 2;
   const int cph = half / N;  // chunks per head-half
   const long total = (long)tokens * heads * cph;
+  // (32-bit index arithmetic with shifts where chunks-per-half and heads are powers of two -- every model here:
+  // the 64-bit divisions by run-time values were ~4/5 of this kernel's instructions and held it at 4.1 TB/s)
+  const bool pow2 = total < 0x7fffffffL && (cph & (cph - 1)) == 0 && (heads & (heads - 1)) == 0;
+  const int sh_c = __builtin_ctz((unsigned)cph), sh_h = __builtin_ctz((unsigned)heads);
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int c = (int)(idx % cph);
-    const long th = idx / cph;
-    const int h = (int)(th % heads);
-    const long t = th / heads;
+    int c, h;
+    long t;
+    if (pow2) {
+      const unsigned u = (unsigned)idx;
+      c = (int)(u & (unsigned)(cph - 1));
+      const unsigned th = u >> sh_c;
+      h = (int)(th & (unsigned)(heads - 1));
+      t = (long)(th >> sh_h);
+    } else {
+      c = (int)(idx % cph);
+      const long th = idx / cph;
+      h = (int)(th % heads);
+      t = th / heads;
+    }
     const int p = pos[t];
     T* xp = x + t * ld + (long)h * hd + c * N;
     const T* cp = cos_t + (long)p * hd + c * N;

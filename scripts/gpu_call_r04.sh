@@ -71,6 +71,13 @@ for step in "$@"; do
       MK_ATTN_XCD_GROUP_CAUSAL=1 timeout 200 python scripts/bench_attn.py > $out/attn_grouped_causal.txt 2>&1
       timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -k "attn or attention or flash or forward_backward" -q -rf --timeout 300 -p no:cacheprovider > $out/t_attn.log 2>&1
       echo "pytest rc=$?" >> $out/t_attn.log ;;
+    mix1)    # round-4 late changes: M-edge idle half, causal sub-block skip, RoPE index arithmetic
+      timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -q -rf --timeout 300 -p no:cacheprovider > $out/t_mix.log 2>&1
+      echo "pytest rc=$?" >> $out/t_mix.log
+      timeout 200 python scripts/bench_attn.py > $out/attn.txt 2>&1
+      GB_COLD=1 GB_ITERS=10 GB_ROUNDS=3 timeout 300 $GB scripts/gemm_shapes_enc.txt > $out/gemm_enc_cold.csv 2> $out/gemm_enc.err
+      timeout 300 python bench.py --config 2 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_cfg2.json 2> $out/bench_cfg2.err
+      timeout 300 python bench.py --steps 8 --warmup 3 --no-cpu-baseline > $out/bench_cfg3.json 2> $out/bench_cfg3.err ;;
     tgemm)
       timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fp8_gpu.py -k "gemm or fp8" -q -rf --timeout 240 -p no:cacheprovider > $out/t_gemm.log 2>&1
       echo "pytest rc=$?" >> $out/t_gemm.log ;;
