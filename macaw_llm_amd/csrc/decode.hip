@@ -84,9 +84,11 @@ __global__ __launch_bounds__(1024) void decode_emit_kernel(const T* logits, long
 #define MK_E16_NS e_f16
 #define decode_attn_kernel decode_attn_f16_kernel
 #define decode_step_attn_kernel decode_step_attn_f16_kernel
+#define decode_step_attn4_kernel decode_step_attn4_f16_kernel
 #include "decode_impl.inc"
 #undef decode_attn_kernel
 #undef decode_step_attn_kernel
+#undef decode_step_attn4_kernel
 #undef MK_E16_T
 #undef MK_E16_NS
 

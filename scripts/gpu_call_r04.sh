@@ -78,6 +78,11 @@ for step in "$@"; do
       GB_COLD=1 GB_ITERS=10 GB_ROUNDS=3 timeout 300 $GB scripts/gemm_shapes_enc.txt > $out/gemm_enc_cold.csv 2> $out/gemm_enc.err
       timeout 300 python bench.py --config 2 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_cfg2.json 2> $out/bench_cfg2.err
       timeout 300 python bench.py --steps 8 --warmup 3 --no-cpu-baseline > $out/bench_cfg3.json 2> $out/bench_cfg3.err ;;
+    decode)  # decode attention for many (sample, head) pairs: four heads per workgroup vs one (A/B), tests
+      timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py tests/test_fullsize_gpu.py -k "decode or generate" -q -rf --timeout 300 -p no:cacheprovider > $out/t_decode.log 2>&1
+      echo "pytest rc=$?" >> $out/t_decode.log
+      timeout 300 python scripts/bench_generate.py 16 32 2>&1 | grep "B=" > $out/generate_attn4.txt
+      MK_DECODE_ATTN_NO4=1 timeout 300 python scripts/bench_generate.py 16 32 2>&1 | grep "B=" > $out/generate_attn1.txt ;;
     tgemm)
       timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fp8_gpu.py -k "gemm or fp8" -q -rf --timeout 240 -p no:cacheprovider > $out/t_gemm.log 2>&1
       echo "pytest rc=$?" >> $out/t_gemm.log ;;

@@ -822,7 +822,10 @@ def test_decode_attn_and_kv_append_with_device_position(hd, H, B, T):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hd,H,B,T", [(128, 32, 1, 173), (128, 4, 2, 1), (64, 8, 2, 65), (32, 4, 2, 300), (16, 4, 3, 40)])
+@pytest.mark.parametrize("hd,H,B,T", [(128, 32, 1, 173), (128, 4, 2, 1), (64, 8, 2, 65), (32, 4, 2, 300), (16, 4, 3, 40),
+                                      # B x H >= 512: the four-heads-per-workgroup kernel (first position, one
+                                      # trip, several trips with a ragged last one)
+                                      (128, 32, 16, 1), (128, 32, 32, 150), (128, 32, 17, 139), (128, 64, 8, 7)])
 def test_decode_step_attn_equals_rope_append_attention(hd, H, B, T):
     """mk_decode_step_attn = mk_rope (q and k heads) + cache append + attention over keys 0 ... p with
     p read from device memory: rotated key / value rows bit-identical to the separate kernels, output
