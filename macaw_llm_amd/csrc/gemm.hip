@@ -547,6 +547,18 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
         }
       }
     }
+    g.walkers = g.dp_tiles;
+    if (t256 && !v8) {
+      // more whole tiles than CUs: one WALKING workgroup per planned CU (tile, tile + walkers, ...), which requests
+      // the first K-tiles of its next tile before the epilogue of the current one (gemm_v7_impl.inc).  The XCD
+      // map needs the stride to be a multiple of 8; batched problems keep one workgroup per tile, and so do
+      // tile counts that are not whole rounds (the hardware's dynamic dispatch balances those better).
+      static const bool no_walk = getenv("MK_GEMM_NO_WALK") != nullptr;
+      if (!no_walk && nbatch == 1 && n_cus % 8 == 0 && g.dp_tiles > n_cus && g.dp_tiles % n_cus == 0) {
+        grid.x = n_cus + (grid.x - g.dp_tiles);
+        g.walkers = n_cus;
+      }
+    }
     if (v8) {
       const int rc = mkg::launch_v8(g, d->a_red_major != 0, d->b_red_major != 0, grid, st, f16);
       mkp::end(prof, st);

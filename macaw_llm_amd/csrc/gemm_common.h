@@ -24,6 +24,7 @@ struct GemmArgs {
   // stream-K tail (v2 kernel only): blocks [0, dp_tiles) own whole tiles; the remaining
   // tiles are cut into `split` K-pieces of `kt_per_piece` K-tiles, one block each.
   int dp_tiles, split, kt_per_piece;
+  int walkers;     // v7: workgroups [0, walkers) walk the whole tiles with stride `walkers`, the rest are the tail
   int tail8;       // v7: the spatial tail is cut into 64 x 128 eighths (K-major A, <= 32 tail tiles) instead of quarters
   int lin_batch;   // 1: batch index is folded into the linear tile index (grid.z == 1)
   int ablate;      // debug only (MK_GEMM_ABLATE): 1 = skip global->LDS, 2 = skip barrier wait
@@ -212,7 +213,8 @@ MK_DEV void wave_epilogue(const f32x16 (&acc)[FM][FN], const GemmArgs& g, ET* C,
 // the accumulators and cost every 16-bit v2 kernel its fourth wave per SIMD (125 -> 136-142 VGPRs).
 template <bool SV, typename ET, int FM, int FN>
 MK_DEV void wave_epilogue16(const f32x16 (&acc)[FM][FN], const GemmArgs& g, ET* C, const ET* Rp,
-                          int m0, int n0, int wm0, int wn0, char* smem) {
+                          int m0, int n0, int wm0, int wn0, char* smem, const bool sync = true,
+                          const int wave_off = -1) {
   typedef typename E16<ET>::x8 e16x8;
   constexpr int W4 = FN * 8;        // float4 per staged row
   constexpr int LPR = W4 / 2;       // lanes per row on the way out (8 columns each)
@@ -225,8 +227,11 @@ MK_DEV void wave_epilogue16(const f32x16 (&acc)[FM][FN], const GemmArgs& g, ET* 
     if (g.scale_a) alpha *= g.scale_a[0];
     if (g.scale_b) alpha *= g.scale_b[0];
   }
-  __syncthreads();                  // every wave is done with the operand tiles in LDS
-  float* buf = reinterpret_cast<float*>(smem) + w * (FN > 2 ? 1024 * FN : 2048);   // 32 rows x FN * 32 fp32 per wave
+  if (sync) __syncthreads();        // every wave is done with the operand tiles in LDS
+  // 32 rows x FN * 32 fp32 per wave; wave_off: the caller's byte offset for this wave (a walking workgroup
+  // keeps the staging buffers out of the ring slots its next tile is already being loaded into)
+  float* buf = wave_off >= 0 ? reinterpret_cast<float*>(smem + wave_off)
+                             : reinterpret_cast<float*>(smem) + w * (FN > 2 ? 1024 * FN : 2048);
   const int srow = l & 31, sh = l >> 5;          // staging: this lane's accumulator row / half
   const int c8 = l % LPR, rsub = l / LPR;        // read-back: 8-column group and row inside a pass
   const int ncol = n0 + wn0 + c8 * 8;            // first of this lane's 8 output columns

@@ -54,6 +54,18 @@ for step in "$@"; do
       [ -n "$f" ] && python scripts/trace_last_step.py "$f" > $out/cfg3_1rank_rccl_last_step.txt 2>&1 ;;
     cuhold)  # GEMMs beside a resident kernel holding 8 / 16 / 32 CUs, planned for 256 or for the free CUs
       timeout 300 scripts/probe/_probe_cu_hold > $out/cu_hold.csv 2> $out/cu_hold.err ;;
+    epi)     # timing-only epilogue ablations of v7 (scripts/probe/build_epi_variants.sh): what overlap could buy
+      for i in 1 2; do
+        GB_COLD=1 GB_ITERS=10 GB_ROUNDS=2 timeout 120 $GB scripts/gemm_shapes_epi.txt > $out/epi_base_$i.csv 2>> $out/epi.err
+        for v in ${EPIVARS:-0 3 4}; do
+          LD_LIBRARY_PATH=scripts/probe/_probe_epi$v GB_COLD=1 GB_ITERS=10 GB_ROUNDS=2 timeout 120 $GB scripts/gemm_shapes_epi.txt > $out/epi_v${v}_$i.csv 2>> $out/epi.err
+        done
+      done ;;
+    walk)    # walking workgroups with the early prologue vs one workgroup per tile (MK_GEMM_NO_WALK), same library
+      for i in 1 2 3; do
+        GB_COLD=1 GB_ITERS=10 GB_ROUNDS=2 timeout 120 $GB scripts/gemm_shapes_walk.txt > $out/walk_on_$i.csv 2>> $out/walk.err
+        MK_GEMM_NO_WALK=1 GB_COLD=1 GB_ITERS=10 GB_ROUNDS=2 timeout 120 $GB scripts/gemm_shapes_walk.txt > $out/walk_off_$i.csv 2>> $out/walk.err
+      done ;;
     enc)
       GB_COLD=1 GB_ITERS=10 GB_ROUNDS=3 timeout 300 $GB scripts/gemm_shapes_enc.txt > $out/gemm_enc_cold.csv 2> $out/gemm_enc.err ;;
     attn)    # attention micro-benchmark (async staging vs the synchronous dq), then the attention / model tests

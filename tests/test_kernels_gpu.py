@@ -91,6 +91,48 @@ def test_gemm_v7_256_tile_kernel(dev, dtype, a_red, b_red, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", H16)
+@pytest.mark.parametrize("a_red,b_red,M,N,K", [
+    (False, False, 4608, 4096, 192),    # 288 tiles: 256 + a 32-tile tail as 64 x 128 eighths
+    (False, True, 4608, 4096, 448),     # ... reduction-major B (transpose reads), nk = 7
+    (False, False, 4600, 4090, 320),    # ... M and N edges inside the tail, unaligned C rows
+    (False, False, 4385, 4096, 64),     # ... tail row group with ONE valid row, nk = 1
+    (False, False, 4096, 8192, 192),    # 512 tiles = two whole rounds: walking workgroups, early prologue
+    (True, True, 8192, 4096, 128),      # ... reduction-major A and B
+    (False, True, 4096, 12288, 320),    # ... three tiles per walker
+])
+def test_gemm_v7_walkers_and_eighth_tail(dev, dtype, a_red, b_red, M, N, K):
+    """more tiles than CUs on the 256 x 256 kernel (round 4): walking workgroups that request the next tile's
+    first K-tiles before the epilogue of the current one (staging moved out of those ring slots), and the
+    eighth-tile tail (not reached by the small shapes of the test above) -- with the full epilogue (alpha,
+    column bias, residual, accumulate) against torch fp32 on the same 16-bit inputs, within one ulp of the
+    128 x 128 kernel, and bit-identical run to run."""
+    from macaw_llm_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    A = _rand((K, M) if a_red else (M, K), dtype, g)
+    B = _rand((K, N) if b_red else (N, K), dtype, g, 0.1)
+    bias, R, C0 = _rand((N,), dtype, g), _rand((M, N), dtype, g), _rand((M, N), dtype, g)
+    ref = 0.5 * ((A.float().t() if a_red else A.float()) @ (B.float() if b_red else B.float().t())) \
+        + bias.float() + R.float() + C0.float()
+    Ad, Bd, bd, Rd = A.to(dev), B.to(dev), bias.to(dev), R.to(dev)
+    outs = {}
+    try:
+        for cfg in (11, 5, 11):
+            lib.mk_gemm_set_cfg(cfg)
+            C = C0.to(dev).clone()
+            ops.gemm_raw(Ad, Bd, C, M, N, K, Ad.stride(0), Bd.stride(0), N, a_red=a_red, b_red=b_red, R=Rd, ldr=N,
+                         bias=bd, bias_mode=1, accumulate=True, alpha=0.5)
+            if cfg == 11 and 11 in outs:
+                assert torch.equal(C, outs[11]), "256 x 256 kernel not reproducible run to run"
+            outs[cfg] = C
+    finally:
+        lib.mk_gemm_set_cfg(-1)
+    _close(outs[11], ref, dtype, scale=0.1 * math.sqrt(K) + 3.0, what=f"v7 walk/tail {M}x{N}x{K} {a_red}{b_red}")
+    d = (outs[11].float() - outs[5].float()).abs().max().item()
+    assert d <= 2 ** -7 * ref.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("dtype", H16)
 @pytest.mark.parametrize("a_red,b_red", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(300, 520, 128), (513, 1000, 192), (1031, 776, 320), (256, 256, 64 * 7),
                                    (2176, 1096, 1024), (512, 768, 4096)])
