@@ -14,6 +14,7 @@
 //   O^T[d][q]  += V^T P^T    P^T fragments are exactly the lane's own S registers (the MFMA
 //                            k-slot <-> key mapping is chosen to match, no cross-lane shuffle)
 // Row max / sum need one __shfl_xor(.., 32) with the partner half.
+#include <utility>
 #include "common.h"
 #include "../../include/macaw_hip.h"
 
@@ -29,11 +30,13 @@
 #define flash_bwd_prep_kernel flash_bwd_prep_f16_kernel
 #define flash_bwd_dq_kernel flash_bwd_dq_f16_kernel
 #define flash_bwd_dkv_kernel flash_bwd_dkv_f16_kernel
+#define flash_bwd_short_kernel flash_bwd_short_f16_kernel
 #include "attention_impl.inc"
 #undef flash_fwd_kernel
 #undef flash_bwd_prep_kernel
 #undef flash_bwd_dq_kernel
 #undef flash_bwd_dkv_kernel
+#undef flash_bwd_short_kernel
 #undef MK_E16_T
 #undef MK_E16_NS
 

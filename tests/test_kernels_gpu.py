@@ -698,6 +698,58 @@ def test_flash_attention_bwd(dev, dtype, hd, Lq, Lk, causal, masked):
         assert torch.isfinite(got).all() and err <= lim, (name, err, lim)
 
 
+@pytest.mark.parametrize("S,causal,masked", [(144, True, True), (160, True, False), (160, False, True), (129, True, False),
+                                             (128, False, False), (96, True, True), (33, True, True), (32, False, False),
+                                             (5, True, False), (1, True, False), (150, False, False)])
+@pytest.mark.parametrize("dtype", H16)
+def test_flash_attention_bwd_short_sequences(dev, dtype, S, causal, masked):
+    """Lq == Lk <= 160 at head_dim 128: ONE kernel per (b, h) runs the D = rowsum(dO * O) pass, dQ and dK / dV
+    (csrc flash_bwd_short_kernel: whole-sequence LDS images with one swizzle for row and transposed reads, 32-row
+    blocks rotated over the waves by (b + h), rows beyond S clamped) -- against fp32 autograd on the same 16-bit
+    inputs; 3 x 3 (b, h) so that every rotation occurs, key-padding mask on one sample, a fully visible and a
+    one-token sequence among the lengths."""
+    g = torch.Generator().manual_seed(S * 31 + causal + 2 * masked)
+    Bn, H, hd = 3, 3, 128
+    D = H * hd
+    q, k, v = (_rand((Bn * S, D), dtype, g, 0.7) for _ in range(3))
+    do = _rand((Bn * S, D), dtype, g)
+    kmask = torch.ones(Bn, S, dtype=torch.int32)
+    if masked:
+        kmask[1, -min(11, S - 1):] = 0
+    km_d = kmask.to(dev) if masked else None
+    scale = hd ** -0.5
+    qd, kd_, vd, dod = q.to(dev), k.to(dev), v.to(dev), do.to(dev)
+    o = torch.zeros((Bn * S, D), dtype=dtype, device=dev)
+    lse = torch.empty((Bn, H, S), dtype=torch.float32, device=dev)
+    geo = (D, S * D, D, S * D, D, S * D, D, S * D)
+    ops.flash_attn_fwd(qd, kd_, vd, o, Bn, H, S, S, hd, *geo, scale, kmask=km_d, causal=causal, lse=lse)
+    nan = float("nan")
+    dq, dk, dv = (torch.full_like(qd, nan) for _ in range(3))
+    ops.flash_attn_bwd(qd, kd_, vd, o, dod, lse, dq, dk, dv, Bn, H, S, S, hd, *geo, scale, kmask=km_d, causal=causal)
+    qf = q.float().view(Bn, S, H, hd).transpose(1, 2).requires_grad_(True)
+    kf = k.float().view(Bn, S, H, hd).transpose(1, 2).requires_grad_(True)
+    vf = v.float().view(Bn, S, H, hd).transpose(1, 2).requires_grad_(True)
+    s = qf @ kf.transpose(-1, -2) * scale
+    if causal:
+        i = torch.arange(S)[:, None]
+        j = torch.arange(S)[None, :]
+        s = s.masked_fill(j > i, float("-inf"))
+    if masked:
+        s = s.masked_fill(kmask[:, None, None, :] == 0, float("-inf"))
+    out = torch.softmax(s, -1) @ vf
+    out.backward(do.float().view(Bn, S, H, hd).transpose(1, 2))
+    for name, got, ref in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
+        ref2 = ref.transpose(1, 2).reshape(Bn * S, D)
+        assert torch.isfinite(got).all(), name + ": rows not written or non-finite"
+        err = (got.float().cpu() - ref2).abs().max().item()
+        lim = 2e-2 * ref2.abs().max().item() + 2e-3
+        assert err <= lim, (name, err, lim)
+    # the same call again: bit-identical (no cross-workgroup state, no atomics)
+    dq2, dk2, dv2 = (torch.full_like(qd, nan) for _ in range(3))
+    ops.flash_attn_bwd(qd, kd_, vd, o, dod, lse, dq2, dk2, dv2, Bn, H, S, S, hd, *geo, scale, kmask=km_d, causal=causal)
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cfg", [19, 22])
 @pytest.mark.parametrize("M,N,K", [(32, 4096, 4096), (17, 1000, 1024), (24, 12288, 4096), (32, 250, 192),
