@@ -74,11 +74,15 @@ MK_DEV float mk_erf(float x) {
 
 template <typename T> MK_DEV float rnd(float v);
 template <> MK_DEV float rnd<float>(float v) { return v; }
+// Round 4: the hardware conversion (v_cvt_pk_bf16_f32: RNE, quiet NaN) + one shift, in asm for the same reason as
+// the fp16 form below.  Rounds 1-3 rounded on the bits (compare, shift, and, add, and: 6 VALU instructions); the
+// in-place RoPE kernel rounds six times per output pair and was VALU-bound on it at 4.4 TB/s
+// (profiles/r04_rope_rnd_ab.txt).  Same values for every finite input; a NaN comes back quiet with a truncated
+// payload instead of unchanged.
 template <> MK_DEV float rnd<bf16>(float v) {
-  uint32_t u = __float_as_uint(v);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return v;  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return __uint_as_float(u & 0xffff0000u);
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(v));
+  return __uint_as_float(r << 16);
 }
 
 // fp16 (the reference's `--fp16 True` / `.to(torch.float16)`, train.sh:36, llm_trainer.py:411-412):
