@@ -31,12 +31,14 @@
 #define flash_bwd_dq_kernel flash_bwd_dq_f16_kernel
 #define flash_bwd_dkv_kernel flash_bwd_dkv_f16_kernel
 #define flash_bwd_short_kernel flash_bwd_short_f16_kernel
+#define flash_fwd_short_kernel flash_fwd_short_f16_kernel
 #include "attention_impl.inc"
 #undef flash_fwd_kernel
 #undef flash_bwd_prep_kernel
 #undef flash_bwd_dq_kernel
 #undef flash_bwd_dkv_kernel
 #undef flash_bwd_short_kernel
+#undef flash_fwd_short_kernel
 #undef MK_E16_T
 #undef MK_E16_NS
 

@@ -85,7 +85,7 @@ for step in "$@"; do
       echo "pytest rc=$?" >> $out/t_attn.log ;;
     shortbwd)  # one-kernel backward for Lq == Lk <= 160, hd 128 vs prep + dq + dkv (MK_ATTN_NO_SHORT_BWD), then the tests
       timeout 200 python scripts/bench_attn.py > $out/attn_short.txt 2>&1
-      MK_ATTN_NO_SHORT_BWD=1 timeout 200 python scripts/bench_attn.py > $out/attn_3kernel.txt 2>&1
+      MK_ATTN_NO_SHORT_BWD=1 MK_ATTN_NO_SHORT_FWD=1 timeout 200 python scripts/bench_attn.py > $out/attn_3kernel.txt 2>&1
       timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -k "attn or attention or flash or forward_backward" -q -rf --timeout 300 -p no:cacheprovider > $out/t_attn.log 2>&1
       echo "pytest rc=$?" >> $out/t_attn.log ;;
     mix1)    # round-4 late changes: M-edge idle half, causal sub-block skip, RoPE index arithmetic

@@ -698,6 +698,52 @@ def test_flash_attention_bwd(dev, dtype, hd, Lq, Lk, causal, masked):
         assert torch.isfinite(got).all() and err <= lim, (name, err, lim)
 
 
+_SHORT_FWD_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from macaw_llm_amd import ops
+dev = torch.device("cuda:0")
+out = {}
+for S, causal, masked in [(144, True, True), (160, False, True), (129, True, False), (33, True, True), (5, True, False)]:
+    g = torch.Generator().manual_seed(S)
+    Bn, H, hd = 3, 3, 128
+    D = H * hd
+    q, k, v = ((torch.randn((Bn * S, D), generator=g) * 0.7).to(torch.bfloat16).to(dev) for _ in range(3))
+    kmask = torch.ones(Bn, S, dtype=torch.int32)
+    if masked:
+        kmask[1, -min(11, S - 1):] = 0
+    o = torch.zeros((Bn * S, D), dtype=torch.bfloat16, device=dev)
+    lse = torch.empty((Bn, H, S), dtype=torch.float32, device=dev)
+    geo = (D, S * D, D, S * D, D, S * D, D, S * D)
+    ops.flash_attn_fwd(q, k, v, o, Bn, H, S, S, hd, *geo, hd ** -0.5, kmask=kmask.to(dev) if masked else None,
+                       causal=causal, lse=lse)
+    out[(S, causal, masked)] = (o.cpu(), lse.cpu())
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_flash_attention_short_forward_is_bit_identical_to_the_tiled_kernel(dev, tmp_path):
+    """Lq == Lk <= 160, head_dim 128: the one-workgroup-per-(b, h) forward (whole-sequence K / V images) keeps
+    flash_fwd_kernel's per-row arithmetic and key-block order, so o and lse are bit-identical to it -- the tiled
+    kernel is selected in a second process with MK_ATTN_NO_SHORT_FWD=1 (the switch is read once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, extra in (("short", {}), ("tiled", {"MK_ATTN_NO_SHORT_FWD": "1"})):
+        f = str(tmp_path / f"{tag}.pt")
+        env = dict(os.environ, **extra)
+        env.pop("MK_ATTN_NO_SHORT_FWD", None) if not extra else None
+        r = subprocess.run([sys.executable, "-c", _SHORT_FWD_SNIPPET, root, f], env=env, capture_output=True, text=True,
+                           timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = torch.load(f)
+    for key, (o, lse) in res["short"].items():
+        o2, lse2 = res["tiled"][key]
+        assert torch.isfinite(o.float()).all()
+        assert torch.equal(o, o2), key
+        assert torch.equal(lse, lse2), key
+
+
 @pytest.mark.parametrize("S,causal,masked", [(144, True, True), (160, True, False), (160, False, True), (129, True, False),
                                              (128, False, False), (96, True, True), (33, True, True), (32, False, False),
                                              (5, True, False), (1, True, False), (150, False, False)])
