@@ -220,11 +220,7 @@ MK_DEV void wave_epilogue16(const f32x16 (&acc)[FM][FN], const GemmArgs& g, ET* 
   constexpr int LPR = W4 / 2;       // lanes per row on the way out (8 columns each)
   constexpr int RPI = 64 / LPR;     // rows per pass
   constexpr int NPASS = 32 / RPI;   // passes per 32-row fragment
-  // (the thread index is laundered: the lane-derived invariants of this epilogue are then formed HERE -- hoisted to
-  // the kernel entry they live through the K loop of a kernel that has no register to spare, in scratch)
-  int tid_ = threadIdx.x;
-  asm volatile("" : "+v"(tid_));
-  const int l = tid_ & 63, w = tid_ >> 6;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   float alpha = g.alpha;
   const bool svec = SV && g.scale_vec != 0;
   if (!svec) {
@@ -242,91 +238,13 @@ MK_DEV void wave_epilogue16(const f32x16 (&acc)[FM][FN], const GemmArgs& g, ET* 
   const bool cols_full = ncol + 7 < g.N;
   // fast path: whole wave on 16-byte aligned, in-range 8-column groups (always true off the N edge)
   const bool fast = g.c_vec == 2 && __all(cols_full ? 1 : 0);
-  // 16-bit staging (round 4): with ONE scale the whole arithmetic -- alpha, bias, activation, residual, accumulate,
-  // in that order, as below -- runs on the accumulator layout (a lane = one row, 4-column groups), the value is
-  // rounded to 16 bits BEFORE the trip through LDS and only 8 bytes per group are staged: half the LDS bytes of
-  // the fp32 form, the same operations per element (bit-identical).  Residual / C / per-column bias are read
-  // as the lane's 4-column groups (8 bytes; the eight loads of a row block are requested before the first use),
-  // the stores stay 16 bytes x 8 rows x 128 bytes per instruction.  The fp32-staged form below remains for the
-  // fp8 kernels (per-row x per-column scales), the one-wave-per-SIMD experiment (FN = 4: the residual rows of a
-  // row block would be 64 more registers) and for edge / unaligned tiles.
-  if constexpr (!SV && FN <= 2) {
-  if (fast) {
-    typedef typename E16<ET>::x4 e16x4;
-    constexpr int RB = FN * 64;                       // staged bytes per row
-    constexpr int W8 = FN * 8;                        // 8-byte words per row
-    constexpr int SHR = FN == 1 ? 2 : (FN == 2 ? 1 : 0);
-    char* b16 = reinterpret_cast<char*>(buf);
-    const int wswz = (srow >> SHR) & (W8 - 1);        // word XOR: rows that share LDS banks get distinct word slots
-    const int ncol4 = n0 + wn0 + 4 * sh;              // + j * 32 + 8 q: first of this lane's 4 staged columns
-    const bool bias8 = g.bias_mode == 1 && (reinterpret_cast<uintptr_t>(g.bias) & 7) == 0;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int ms = m0 + wm0 + i * 32 + srow;
-      const long mc = min(ms, g.M - 1);
-      const float bm = g.bias_mode == 2 ? (float)reinterpret_cast<const ET*>(g.bias)[mc] : 0.f;
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        e16x4 rv[4], cv[4];       // (per 32-column fragment: a whole row block at once costs the kernel its last registers)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (Rp) rv[q] = *reinterpret_cast<const e16x4*>(Rp + mc * g.ldr + ncol4 + j * 32 + 8 * q);
-          if (g.accumulate) cv[q] = *reinterpret_cast<const e16x4*>(C + mc * g.ldc + ncol4 + j * 32 + 8 * q);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = alpha * acc[i][j][4 * q + e];
-          if (g.bias_mode == 1) {
-            const ET* bp = reinterpret_cast<const ET*>(g.bias) + ncol4 + j * 32 + 8 * q;
-            if (bias8) {
-              const e16x4 b4 = *reinterpret_cast<const e16x4*>(bp);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)b4[e];
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)bp[e];
-            }
-          } else if (g.bias_mode == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bm;
-          }
-          if (g.act) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], g.act);
-          }
-          if (Rp) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rv[q][e];
-          }
-          if (g.accumulate) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)cv[q][e];
-          }
-          e16x4 o4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o4[e] = (ET)v[e];
-          *reinterpret_cast<e16x4*>(b16 + srow * RB + (((j * 8 + 2 * q + sh) ^ wswz) << 3)) = o4;
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        const int row = p * RPI + rsub, m = m0 + wm0 + i * 32 + row;
-        const int x = (row >> SHR) & (W8 - 1);
-        const e16x4 lo = *reinterpret_cast<const e16x4*>(b16 + row * RB + (((2 * c8) ^ x) << 3));
-        const e16x4 hi = *reinterpret_cast<const e16x4*>(b16 + row * RB + (((2 * c8 + 1) ^ x) << 3));
-        if (m < g.M) {
-          e16x8 o;
-          o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-          o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
-          *reinterpret_cast<e16x8*>(C + (long)m * g.ldc + ncol) = o;
-        }
-      }
-    }
-    return;
-  }
-  }
+  // (Round 4, measured and removed: 16-bit staging -- alpha / bias / activation on the accumulator layout, the value
+  // rounded BEFORE the trip through LDS, 8 bytes per 4-column group staged: half the LDS bytes, bit-identical.
+  // Cold in the harness +0.3 ... +7 % per launch; in the cfg-3 step -1.1 % of GEMM time, with the residual rows
+  // read on the accumulator layout as well -1.2 % (gpurun_out/r04/l3, l4).  On the way: laundering the thread
+  // index at the top of this function stops the compiler from forming the epilogue's lane invariants at the kernel
+  // entry and takes the 256 x 256 kernel from 251 to 213-227 VGPRs -- and costs 0.7 % of GEMM time in the step
+  // (170.3 vs 169.1 ms, three alternations on one box, gpurun_out/r04/l5): not kept either.)
   float sb[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};      // per-column de-quantisation scales (fp8, scale_vec)
   if (svec) {
 #pragma unroll

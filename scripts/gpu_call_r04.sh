@@ -66,11 +66,6 @@ for step in "$@"; do
         GB_COLD=1 GB_ITERS=10 GB_ROUNDS=2 timeout 120 $GB scripts/gemm_shapes_walk.txt > $out/walk_on_$i.csv 2>> $out/walk.err
         MK_GEMM_NO_WALK=1 GB_COLD=1 GB_ITERS=10 GB_ROUNDS=2 timeout 120 $GB scripts/gemm_shapes_walk.txt > $out/walk_off_$i.csv 2>> $out/walk.err
       done ;;
-    lean)    # 16-bit staged epilogue for tiles without residual / accumulate vs the fp32-staged form (variant library)
-      for i in 1 2 3; do
-        GB_COLD=1 GB_ITERS=10 GB_ROUNDS=2 timeout 120 $GB scripts/gemm_shapes_walk.txt > $out/lean_on_$i.csv 2>> $out/lean.err
-        LD_LIBRARY_PATH=scripts/probe/_probe_nolean GB_COLD=1 GB_ITERS=10 GB_ROUNDS=2 timeout 120 $GB scripts/gemm_shapes_walk.txt > $out/lean_off_$i.csv 2>> $out/lean.err
-      done ;;
     enc)
       GB_COLD=1 GB_ITERS=10 GB_ROUNDS=3 timeout 300 $GB scripts/gemm_shapes_enc.txt > $out/gemm_enc_cold.csv 2> $out/gemm_enc.err ;;
     attn)    # attention micro-benchmark (async staging vs the synchronous dq), then the attention / model tests
