@@ -97,6 +97,9 @@ __global__ __launch_bounds__(256) void softmax_fwd_wave_kernel(
 
 // One 256-thread block per row (long rows, e.g. the 32,009-key alignment attention): three
 // vectorised passes (max, sum, write); the row (<= 64 KiB) stays in L2 between passes.
+// (Round 4, measured and removed: the row held in registers between the passes -- 16 raw 16-byte chunks per
+// thread, read once -- is SLOWER, forward 231 vs 195 us and backward 276 vs 190 us at 3072 rows x 32,009: at
+// 114 / 178 VGPRs fewer rows are in flight per CU, and the second and third pass hit L2 anyway.)
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_fwd_block_kernel(
     const T* scores, T* probs, T* probs_drop, const int32_t* kmask, int heads, int Lq, int Lk,
