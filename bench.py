@@ -293,7 +293,7 @@ def main():
             dist.init_process_group(backend=backend, **kw)
 
     from macaw_llm_amd import ops
-    from macaw_llm_amd.bucketed import BucketedStep
+    from macaw_llm_amd.bucketed import BucketedStep, default_comm_cus
     from macaw_llm_amd.factory import baseline_config, build_model, synthetic_inputs
     from macaw_llm_amd.optim import FusedAdamW
 
@@ -322,8 +322,7 @@ def main():
         o = FusedAdamW(params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
         return BucketedStep(params, o, model=model, overlap=not os.environ.get("MACAW_NO_OVERLAP"),
                             force_collectives=force_coll, zero1=zero1,
-                            comm_cus=int(os.environ.get("MACAW_COMM_CUS", os.environ.get("NCCL_MAX_NCHANNELS", "0")))
-                            if world > 1 else 0,
+                            comm_cus=default_comm_cus() if (world > 1 or force_coll) else 0,
                             bucket_bytes=int(os.environ.get("MACAW_BUCKET_MB", "768")) << 20)
 
     runtime = make_runtime()

@@ -86,6 +86,21 @@ def shard_batch(global_batch: int, rank: int, world: int):
     return rank * per, (rank + 1) * per
 
 
+def default_comm_cus() -> int:
+    """CUs the GEMMs leave to the collective kernels while a window's collectives are in flight: MACAW_COMM_CUS if
+    set, else the RCCL channel cap NCCL_MAX_NCHANNELS (one resident workgroup = one CU per channel), else 16 -- the
+    cap bench.py and hf.py put into the environment.  The value is chosen by profiles/r05_overlap_1rank.txt."""
+    import os
+    for k in ("MACAW_COMM_CUS", "NCCL_MAX_NCHANNELS"):
+        v = os.environ.get(k)
+        if v:
+            try:
+                return max(0, int(v))
+            except ValueError:
+                pass
+    return 16
+
+
 class DynamicLossScaler:
     """deepspeed.runtime.fp16.loss_scaler.DynamicLossScaler with the reference's settings as defaults
     (configs/deepspeed_config.json:14-21).  update(overflow) after every optimizer step attempt:
@@ -360,6 +375,9 @@ class BucketedStep:
         """call before the backward of every micro-batch"""
         first = self._micro == 0
         if first:
+            # a backward / finish() that raised (OOM, a refused optimizer state, a retried step) must not leave the
+            # process-global GEMM planning limit behind: every window starts with the whole chip (ADVICE r4)
+            self._reserve_cus(False)
             if hasattr(self.opt, "uniform_hyper") and not self.opt.uniform_hyper():
                 raise ValueError("BucketedStep: the optimizer's parameter groups differ in lr / betas / eps / "
                                  "weight_decay; the bucket runtime updates every parameter with one launch "
@@ -517,6 +535,20 @@ class BucketedStep:
             self._micro += 1
             return
         self._micro = 0
+        try:
+            self._finish_window()
+        finally:
+            # also when the window raised: eval / generate / the next step plan for the whole chip again
+            self._reserve_cus(False)
+
+    def abort(self):
+        """drop a window whose forward / backward raised (the caller will not reach finish()): the direct
+        gradient destinations and the GEMM planning limit are process-global and must not outlive it"""
+        self._micro = 0
+        self._install_dst(False)
+        self._reserve_cus(False)
+
+    def _finish_window(self):
         self._install_dst(False)
         if self._comm is not None and self.params[0].is_cuda:
             self._comm["ev0"] = torch.cuda.Event(enable_timing=True)
@@ -554,6 +586,7 @@ class BucketedStep:
             h.wait()
         self._gathers.clear()
         self._reserve_cus(False)                # the forward has the whole chip again
+                                                # (finish() repeats this in its `finally`)
         if self._comm is not None and self.params[0].is_cuda:
             self._comm["ev1"] = torch.cuda.Event(enable_timing=True)
             self._comm["ev1"].record()          # the step is complete on the compute stream
@@ -592,6 +625,7 @@ class BucketedStep:
             h.remove()
         self._hooks.clear()
         self._install_dst(False)
+        self._reserve_cus(False)
         for b in self.buckets:
             ops.PINNED_STORAGE.discard(b.w.untyped_storage().data_ptr())
         ops.clear_fp8_cache()                   # e4m3 copies of weights that lived in these buckets

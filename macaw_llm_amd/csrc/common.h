@@ -161,6 +161,7 @@ template <typename T> struct E16;
 template <> struct E16<bf16> {
   typedef bf16x8 x8; typedef bf16x4 x4;
   static constexpr int dtype = MK_BF16;
+  static constexpr bool narrow_exponent = false;
   MK_DEV static f32x16 mma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
   MK_DEV static f32x4 mma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
   MK_DEV static x4 tr_read(const char* lds) {
@@ -179,6 +180,10 @@ template <> struct E16<bf16> {
 template <> struct E16<_Float16> {
   typedef f16x8 x8; typedef f16x4 x4;
   static constexpr int dtype = MK_F16;
+  // 5 exponent bits: a value rounded to this type inside a kernel keeps its natural scaling (the attention
+  // backward multiplies dS by the softmax scale BEFORE rounding it, as the reference's fp16 graph does: without it
+  // dS has 1/scale = 11x less headroom under the 2^16 dynamic loss scale -- ADVICE r4)
+  static constexpr bool narrow_exponent = true;
   MK_DEV static f32x16 mma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
   MK_DEV static f32x4 mma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
   MK_DEV static x4 tr_read(const char* lds) {

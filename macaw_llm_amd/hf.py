@@ -28,17 +28,29 @@ checkpoint cadence, `save_model`, `resume_from_checkpoint` stay HF's):
     pass-through module when more than one rank trains.
   * checkpoints: `optimizer.state_dict()` carries this rank's fp32 master / moment shards, the bucket layout they
     are keyed by and the dynamic loss scaler (fp16); `load_state_dict` refuses another world size / rank /
-    bucket size instead of silently restarting the moments.
+    bucket size instead of silently restarting the moments.  With N > 1 ranks under ZeRO-1 every rank owns a
+    different slice of the optimizer state, so `_save_optimizer_and_scheduler` / `_load_optimizer_and_scheduler`
+    write and read ONE FILE PER RANK (`optimizer_rank{r}-of-{N}.pt`, as DeepSpeed's `*_optim_states.pt`); HF's
+    stock code would save rank 0's shards only and hand them to every rank on resume.  N = 1 keeps HF's
+    `optimizer.pt`.
+  * the GEMMs plan for `comm_cus` fewer CUs while collectives are in flight (`bucketed.default_comm_cus()`: the
+    RCCL channel cap, 16 unless NCCL_MAX_NCHANNELS / MACAW_COMM_CUS say otherwise -- the same default `bench.py`
+    uses), and the LR scheduler does not advance on a step the dynamic loss scaler skipped (DeepSpeed's rule).
 
 `--deepspeed configs/deepspeed_config.json` (train.sh:16) is NOT used with this mixin: the runtime IS the ZeRO-1
 equivalent ("DeepSpeed").
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
-from .bucketed import BucketedStep, DynamicLossScaler
+from .bucketed import BucketedStep, DynamicLossScaler, default_comm_cus
 from .optim import FusedAdamW
+
+# the channel cap has to be in the environment before RCCL builds its communicator (the first collective)
+os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
 
 
 class _PassThrough(torch.nn.Module):
@@ -71,6 +83,7 @@ class MacawTrainerMixin:
     macaw_bucket_bytes = 768 << 20      # flat bucket size (bucketed.BucketedStep)
     macaw_zero1 = True                  # ZeRO-1 (reduce-scatter / shard AdamW / all-gather); False: all-reduce
     macaw_dynamic_loss_scale = None     # None: on iff the parameters are fp16 (configs/deepspeed_config.json:14-21)
+    macaw_comm_cus = None               # CUs left to the collective kernels; None: bucketed.default_comm_cus()
 
     # ---- optimizer -------------------------------------------------------------------------------------------
     def create_optimizer(self, model=None):
@@ -99,10 +112,62 @@ class MacawTrainerMixin:
             rt = BucketedStep(None, opt, model=self.model, bucket_bytes=self.macaw_bucket_bytes,
                               accumulate_steps=a.gradient_accumulation_steps,
                               max_grad_norm=a.max_grad_norm if (a.max_grad_norm or 0) > 0 else None,
-                              zero1=self.macaw_zero1, loss_scaler=scaler)
+                              zero1=self.macaw_zero1, loss_scaler=scaler,
+                              comm_cus=default_comm_cus() if self.macaw_comm_cus is None else int(self.macaw_comm_cus))
             opt.attach_runtime(rt)
             self._macaw_rt = rt
         return rt
+
+    # ---- LR schedule: a step the loss scaler skipped does not count (DeepSpeed) --------------------
+    def create_scheduler(self, num_training_steps, optimizer=None):
+        sched = super().create_scheduler(num_training_steps, optimizer=optimizer)
+        sched = sched if sched is not None else self.lr_scheduler
+        if sched is not None and not getattr(type(sched), "_macaw_wrapped", False):
+            trainer, base = self, type(sched)
+
+            def step(sched_self, *a, **kw):
+                rt = getattr(trainer, "_macaw_rt", None)
+                if rt is not None and rt.last_step_skipped:
+                    return None
+                return base.step(sched_self, *a, **kw)
+
+            # a subclass, not an instance attribute: LRScheduler.state_dict() is the instance __dict__
+            sched.__class__ = type(base.__name__, (base,), {"step": step, "_macaw_wrapped": True})
+        return sched
+
+    # ---- checkpoints: one optimizer file per rank under ZeRO-1 ------------------------------------
+    def _macaw_sharded(self) -> bool:
+        return (torch.distributed.is_available() and torch.distributed.is_initialized()
+                and torch.distributed.get_world_size() > 1 and self.macaw_zero1)
+
+    @staticmethod
+    def _macaw_opt_file(rank: int, world: int) -> str:
+        return f"optimizer_rank{rank}-of-{world}.pt"
+
+    def _save_optimizer_and_scheduler(self, output_dir):
+        if not self._macaw_sharded():
+            return super()._save_optimizer_and_scheduler(output_dir)
+        r, n = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        os.makedirs(output_dir, exist_ok=True)
+        torch.save(unwrap_optimizer(self.optimizer).state_dict(), os.path.join(output_dir, self._macaw_opt_file(r, n)))
+        if self.args.should_save:
+            torch.save(self.lr_scheduler.state_dict(), os.path.join(output_dir, "scheduler.pt"))
+        torch.distributed.barrier()          # rotation / the next step must not race a rank that is still writing
+
+    def _load_optimizer_and_scheduler(self, checkpoint):
+        if checkpoint is None or not self._macaw_sharded():
+            return super()._load_optimizer_and_scheduler(checkpoint)
+        r, n = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        f = os.path.join(checkpoint, self._macaw_opt_file(r, n))
+        if not os.path.isfile(f):
+            others = sorted(x for x in os.listdir(checkpoint) if x.startswith("optimizer_rank"))
+            raise FileNotFoundError(
+                f"MacawTrainerMixin: {f} not found (the checkpoint holds {others or 'no per-rank optimizer files'}): "
+                "ZeRO-1 optimizer shards resume into the world size they were written with")
+        unwrap_optimizer(self.optimizer).load_state_dict(torch.load(f, map_location=self.args.device, weights_only=True))
+        sf = os.path.join(checkpoint, "scheduler.pt")
+        if os.path.isfile(sf):
+            self.lr_scheduler.load_state_dict(torch.load(sf, map_location="cpu", weights_only=True))
 
     def _wrap_model(self, model, training=True, dataloader=None):
         if training and torch.distributed.is_available() and torch.distributed.is_initialized() \

@@ -47,6 +47,10 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(groups, dict(lr=float(lr), betas=tuple(betas), eps=float(eps),
                                       weight_decay=float(weight_decay)))
         self.step_count = 0
+        self._hp_override = None  # the group step() is updating (its lr / betas / eps / weight_decay): see _hp
+        self._index = {}          # id(parameter) -> position in the checkpoint's numbering (stable: never derived
+        self._reindex()           # from a temporarily narrowed param_groups -- ADVICE r4)
+        self._stashed = None      # loss-scaler state / layout of a checkpoint loaded before the runtime existed
         self._pending = {}        # loaded state waiting for its (lazily created) slot: see load_state_dict
         self._loaded_keys = None  # key names of the last load_state_dict (None: nothing was loaded)
         self._loaded_layout = None
@@ -56,8 +60,17 @@ class FusedAdamW(torch.optim.Optimizer):
     def params(self):
         return [p for g in self.param_groups for p in g["params"]]
 
+    def _reindex(self):
+        self._index = {id(p): i for i, p in enumerate(p for g in self.param_groups for p in g["params"])}
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, "_index"):
+            self._reindex()
+
     def _hp(self, name):
-        return self.param_groups[0][name]
+        g = self._hp_override if self._hp_override is not None else self.param_groups[0]
+        return g[name]
 
     def _set_hp(self, name, v):
         for g in self.param_groups:
@@ -72,10 +85,21 @@ class FusedAdamW(torch.optim.Optimizer):
     def attach_runtime(self, runtime):
         """the bucket runtime that owns the update from now on (hf.MacawTrainerMixin): `step()` becomes a no-op
         (the update happens in runtime.finish()), `state_dict()` / `load_state_dict()` carry and check the
-        runtime's bucket layout and its dynamic loss scaler"""
+        runtime's bucket layout and its dynamic loss scaler.  A checkpoint loaded BEFORE the runtime existed (HF's
+        Trainer restores the optimizer ahead of the first training_step, which is where the mixin builds the
+        runtime) left its loss-scaler state and layout stashed: they are applied / verified here."""
         import weakref
         self._runtime_steps = True
         self._runtime_ref = weakref.ref(runtime)
+        st, self._stashed = self._stashed, None
+        if st is not None:
+            saved, scaler = st
+            layout = runtime.layout()
+            if saved is not None and saved != layout:
+                raise ValueError(f"FusedAdamW: the checkpoint loaded before the runtime was built has layout {saved}, "
+                                 f"this runtime has {layout} (ZeRO-1 shards are per world size / rank / bucket size)")
+            if scaler is not None and runtime.loss_scaler is not None:
+                runtime.loss_scaler.load_state_dict(scaler)
 
     def _runtime(self):
         ref = getattr(self, "_runtime_ref", None)
@@ -105,10 +129,13 @@ class FusedAdamW(torch.optim.Optimizer):
     def _key_name(self, key):
         if isinstance(key, tuple):
             return "shard:%d:%d:%d" % key             # (bucket, first element, elements) of bucketed.BucketedStep
-        for i, p in enumerate(self.params):
-            if p is key:
-                return "param:%d" % i
-        raise KeyError("FusedAdamW: state of a parameter that is not in self.params")
+        i = self._index.get(id(key))
+        if i is None:
+            self._reindex()                           # (param_groups edited in place by the caller)
+            i = self._index.get(id(key))
+        if i is None:
+            raise KeyError("FusedAdamW: state of a parameter that is not in self.params")
+        return "param:%d" % i
 
     def _restore(self, key, st):
         if self._loaded_keys is None:
@@ -167,6 +194,8 @@ class FusedAdamW(torch.optim.Optimizer):
             layout = rt.layout()
         if rt is not None and rt.loss_scaler is not None and sd.get("loss_scaler") is not None:
             rt.loss_scaler.load_state_dict(sd["loss_scaler"])
+        if rt is None and layout is None and (saved is not None or sd.get("loss_scaler") is not None):
+            self._stashed = (saved, sd.get("loss_scaler"))      # applied / verified in attach_runtime()
         if layout is not None and saved is not None and saved != layout:
             raise ValueError(f"FusedAdamW.load_state_dict: the checkpoint was written with layout {saved}, this "
                              f"runtime has {layout} (ZeRO-1 shards are per world size / rank / bucket size; re-shard "
@@ -441,11 +470,10 @@ class FusedAdamW(torch.optim.Optimizer):
         if len(self.param_groups) == 1:
             self.step_params(self.param_groups[0]["params"], grad_scale)
         else:
-            saved = self.param_groups
             try:
-                for g in saved:                       # the kernels read group 0's values: one group at a time
-                    self.param_groups = [g]
-                    self.step_params(g["params"], grad_scale)
+                for g in self.param_groups:           # one group at a time, each with its OWN hyper-parameters
+                    self._hp_override = g             # (param_groups itself is never narrowed: the checkpoint
+                    self.step_params(g["params"], grad_scale)   # key of a parameter is its global position)
             finally:
-                self.param_groups = saved
+                self._hp_override = None
         return loss

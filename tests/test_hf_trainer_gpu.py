@@ -173,3 +173,80 @@ def test_trainer_optimizer_checkpoint_carries_the_layout_and_refuses_another(dev
     step(D, rd)
     assert od.step_count == 2 and not od._pending
     rd.remove()
+
+
+def test_mixin_runtime_reserves_cus_for_the_collectives_like_bench_py(dev, monkeypatch, tmp_path):
+    """`hf.py` built BucketedStep without `comm_cus`, so the reference's own driver route would
+    have run N > 1 with every GEMM planned for all 256 CUs beside the resident RCCL channels."""
+    from transformers import TrainingArguments, default_data_collator
+    from macaw_llm_amd.bucketed import default_comm_cus
+    monkeypatch.delenv("MACAW_COMM_CUS", raising=False)
+    fx = load_case("micro_all")
+    cfg = configs.get(fx["config_name"])
+    model = build_model(cfg, fx["state"], torch.float32, dev, fuse=True)
+    args = TrainingArguments(output_dir=str(tmp_path / "o"), per_device_train_batch_size=2, max_steps=1,
+                             save_strategy="no", report_to=[], remove_unused_columns=False, dataloader_pin_memory=False)
+    tr = _trainer_cls()(model=model, args=args, train_dataset=_Samples(fx["inputs"], 2), data_collator=default_data_collator)
+    tr.create_optimizer()
+    rt = tr.macaw_runtime()
+    # one rank: no collective, nothing to reserve -- the value is carried and takes effect as soon as world > 1
+    assert rt.comm_cus == 0 and not rt.collective
+    assert default_comm_cus() == int(__import__("os").environ["NCCL_MAX_NCHANNELS"]) > 0
+    rt.remove()
+    cls = _trainer_cls()
+    cls.macaw_comm_cus = 24
+    import macaw_llm_amd.hf as H
+    seen = {}
+    real = H.BucketedStep
+
+    def spy(*a, **kw):
+        seen.update(kw)
+        return real(*a, **kw)
+
+    monkeypatch.setattr(H, "BucketedStep", spy)
+    tr2 = cls(model=model, args=args, train_dataset=_Samples(fx["inputs"], 2), data_collator=default_data_collator)
+    tr2.create_optimizer()
+    tr2.macaw_runtime().remove()
+    assert seen["comm_cus"] == 24
+
+
+def test_two_group_optimizer_resumes_every_slot_from_its_own_entry(dev):
+    """ADVICE r4 (medium), on the real kernels: two parameter groups of identically shaped tensors, save after two
+    steps, load into a fresh optimizer, step both: bit-identical to the optimizer that never stopped."""
+    from macaw_llm_amd.optim import FusedAdamW
+    torch.manual_seed(3)
+
+    def make():
+        g = torch.Generator().manual_seed(5)
+        ps = [torch.nn.Parameter(torch.randn(64, 64, generator=g).to(dev, torch.bfloat16)) for _ in range(4)]
+        opt = FusedAdamW([dict(params=ps[:2], lr=1e-2), dict(params=ps[2:], lr=3e-3, weight_decay=0.1)])
+        return ps, opt
+
+    def grads(ps, k):
+        g = torch.Generator().manual_seed(100 + k)
+        for i, p in enumerate(ps):
+            p.grad = (torch.randn(64, 64, generator=g) * (i + 1)).to(dev, torch.bfloat16)
+
+    A, oa = make()
+    for k in range(2):
+        grads(A, k)
+        oa.step()
+    sd = {k: (v if k != "state" else {n: {m: t.clone() for m, t in e.items()} for n, e in v.items()})
+          for k, v in oa.state_dict().items()}
+    assert sorted(sd["state"]) == ["param:0", "param:1", "param:2", "param:3"]
+    B, ob = make()
+    with torch.no_grad():
+        for a, b in zip(A, B):
+            b.copy_(a)
+    ob.load_state_dict(sd)
+    for k in range(2, 4):
+        grads(A, k)
+        oa.step()
+        grads(B, k)
+        ob.step()
+    torch.cuda.synchronize()
+    ob.assert_restored()
+    for i, (a, b) in enumerate(zip(A, B)):
+        assert torch.equal(a, b), i
+        for x, y in zip(oa.state[a], ob.state[b]):
+            assert torch.equal(x, y), i
