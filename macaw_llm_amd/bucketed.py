@@ -101,6 +101,32 @@ def default_comm_cus() -> int:
     return 16
 
 
+_OVERLAP_GROUP = {}
+
+
+def overlap_group():
+    """The process group the bucket collectives run on when the caller passes none: all ranks, RCCL, and its
+    kernels on a HIGH-PRIORITY stream.  Why (profiles/r05_overlap_1rank.txt): HIP maps streams to a handful of
+    hardware queues; the stream torch hands the default group came out on the SAME hardware queue as the compute
+    stream on the boxes measured, so every collective kernel was serialised with the GEMMs submitted around it --
+    "overlapped 0.00 ms" whatever the GEMMs planned for.  Streams of another priority live in another pool of
+    hardware queues: the collective's 16 resident workgroups are dispatched beside the GEMM that left them 16 CUs
+    (BucketedStep(comm_cus)), and first when both wait for a CU.  MACAW_COMM_NORMAL_PRIORITY=1 keeps the default
+    group (A/B).  Returns (group or None, note for the bench line)."""
+    import os
+    if os.environ.get("MACAW_COMM_NORMAL_PRIORITY"):
+        return None, "default process group (normal-priority stream: MACAW_COMM_NORMAL_PRIORITY)"
+    key = dist.get_world_size()
+    if key not in _OVERLAP_GROUP:
+        try:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            _OVERLAP_GROUP[key] = (dist.new_group(backend="nccl", pg_options=opts),
+                                   "own RCCL group on a high-priority stream")
+        except Exception as e:      # noqa: BLE001  (an older torch without the option: the default group works)
+            _OVERLAP_GROUP[key] = (None, f"default process group (no high-priority group: {e!r})"[:160])
+    return _OVERLAP_GROUP[key]
+
+
 class DynamicLossScaler:
     """deepspeed.runtime.fp16.loss_scaler.DynamicLossScaler with the reference's settings as defaults
     (configs/deepspeed_config.json:14-21).  update(overflow) after every optimizer step attempt:
@@ -208,12 +234,15 @@ class BucketedStep:
         if not self.params:
             raise ValueError("no trainable parameters")
         self.opt = opt
-        self.group = process_group
         init = dist.is_initialized()
         self.world = dist.get_world_size(process_group) if init else 1
         self.rank = dist.get_rank(process_group) if init else 0
         self._avg = init and dist.get_backend(process_group) == "nccl"   # gloo has no AVG
         self.collective = self.world > 1 or (force_collectives and init)
+        self.group = process_group
+        self.group_note = "caller's process group"
+        if process_group is None and self.collective and overlap and self._avg:
+            self.group, self.group_note = overlap_group()
         self.zero1 = bool(zero1)
         self.accumulate_steps = max(1, int(accumulate_steps))
         self.average_accumulated = bool(average_accumulated)
@@ -699,6 +728,7 @@ class BucketedStep:
                 "rs_total_ms": tot(rs), "ag_total_ms": tot(ag),
                 "rs_bytes": sum(n for _, _, n in rs), "ag_bytes": sum(n for _, _, n in ag),
                 "bucket_order": [i for i, _, _ in rs],
+                "comm_cus": self.comm_cus, "group": self.group_note if self.collective else None,
                 "timing": "per-collective device time from the process group (TORCH_NCCL_ENABLE_TIMING)"
                 if any(d is not None for _, d, _ in rs + ag) else "collectives not timed by this backend"}
 
@@ -718,4 +748,5 @@ class BucketedStep:
                    + (" (mean)" if self.average_accumulated else " (sum)") if self.accumulate_steps > 1 else "")
                 + (f", clip {self.max_grad_norm}" if self.max_grad_norm is not None else "")
                 + (f", dynamic loss scale {self.loss_scale:g}" if self.loss_scaler is not None else "")
-                + (f", GEMMs plan for {self.comm_cus} fewer CUs while collectives are in flight" if self.comm_cus else ""))
+                + (f", GEMMs plan for {self.comm_cus} fewer CUs while collectives are in flight" if self.comm_cus else "")
+                + (f", collectives on {self.group_note}" if self.collective else ""))

@@ -19,7 +19,7 @@ CSRC = PKG / "csrc"
 OBJ = PKG / "csrc" / "_obj"
 LIB = PKG / "libmacaw_hip.so"
 ARCH = "gfx950"
-SOURCES = ["gemm.hip", "gemm_v7.hip", "gemm_v8.hip", "norm.hip", "elementwise.hip", "softmax.hip", "attention.hip",
+SOURCES = ["gemm.hip", "gemm_v7.hip", "gemm_v8.hip", "gemm_v9.hip", "norm.hip", "elementwise.hip", "softmax.hip", "attention.hip",
            "decode.hip", "preprocess.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", *os.environ.get("MK_EXTRA_FLAGS", "").split(),
          "-Wno-unused-result"]
@@ -28,7 +28,8 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
 # per-source flags.  gemm_v8.hip: the LDS-transposed epilogue of a 4 x 4-fragment wave tile exceeds LLVM's
 # default `#pragma unroll` size budget; left rolled, the fragment-row loop indexes the 256 accumulator
 # registers dynamically and the whole accumulator goes through scratch memory.
-FILE_FLAGS = {"gemm_v8.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
+FILE_FLAGS = {"gemm_v8.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
+              "gemm_v9.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
 
 
 def _hipcc() -> str:

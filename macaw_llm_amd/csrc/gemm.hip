@@ -288,6 +288,7 @@ extern "C" int mk_gemm_set_cus(int n) { const int prev = g_plan_cus; g_plan_cus 
 namespace mkg {
 int launch_v7(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st, bool fp8, bool f16);  // gemm_v7.hip
 int launch_v8(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st, bool f16);            // gemm_v8.hip
+int launch_v9(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st, bool f16);            // gemm_v9.hip
 }
 
 // y[M <= 16, N] = prologue(x) W^T (+ residual): the linear layers of one decode position per sample
@@ -472,9 +473,11 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     if (env_cfg >= 0) cfg = env_cfg;
     else cfg = pick_cfg(d, nbatch, v7_ok, n_cus);
     if (fp8 && cfg != 11) cfg = 5;        // fp8 exists on the two LDS-DMA tile kernels only
-    if ((cfg == 11 || cfg == 14) && !v7_ok) cfg = 5;
-    if (cfg == 14 && fp8) cfg = 11;       // (v8 has no e4m3 instantiation yet)
-    if (cfg != 0 && cfg != 5 && cfg != 7 && cfg != 11 && cfg != 14) cfg = 5;
+    if ((cfg == 11 || cfg == 14 || cfg == 15) && !v7_ok) cfg = 5;
+    if ((cfg == 14 || cfg == 15) && fp8) cfg = 11;       // (v8 / v9 have no e4m3 instantiation)
+    // v9 (hand-placed K loop, gemm_v9.hip) takes whole 256 x 256 x 64 tiles only
+    if (cfg == 15 && (d->M % 256 != 0 || d->N % 256 != 0 || d->K % 64 != 0)) cfg = 11;
+    if (cfg != 0 && cfg != 5 && cfg != 7 && cfg != 11 && cfg != 14 && cfg != 15) cfg = 5;
     if (cfg >= 5 && !v2_ok) cfg = 0;
     if (fp8 && cfg != 5 && cfg != 11) return MK_ERR_UNSUPPORTED;
     // Measured (profiles/): with BOTH operands reduction-major (dW = dy^T x) the global rows are
@@ -484,7 +487,8 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     const int bkv = cfg == 7 ? 32 : BK;
     mkp::set_cfg(prof, cfg);
     const bool v8 = cfg == 14;            // 256 x 256 tile, one wave per SIMD (gemm_v8.hip)
-    const bool t256 = cfg == 11 || v8;
+    const bool v9 = cfg == 15;            // the same with the K loop placed by hand (gemm_v9.hip)
+    const bool t256 = cfg == 11 || v8 || v9;
     const int bm = t256 ? 256 : 128;
     const int bn = t256 ? 256 : BN;
     g.tiles_m = mk_cdiv(d->M, bm);
@@ -548,7 +552,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
       }
     }
     g.walkers = g.dp_tiles;
-    if (t256 && !v8) {
+    if (t256 && !v8 && !v9) {
       // more whole tiles than CUs: one WALKING workgroup per planned CU (tile, tile + walkers, ...), which requests
       // the first K-tiles of its next tile before the epilogue of the current one (gemm_v7_impl.inc).  The XCD
       // map needs the stride to be a multiple of 8; batched problems keep one workgroup per tile, and so do
@@ -561,6 +565,21 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     }
     if (v8) {
       const int rc = mkg::launch_v8(g, d->a_red_major != 0, d->b_red_major != 0, grid, st, f16);
+      mkp::end(prof, st);
+      return rc;
+    }
+    if (v9 && g.dp_tiles >= n_cus) {
+      // whole tiles [0, dp_tiles) on v9, one workgroup each; the spatial tail of the last partial round (planned
+      // above exactly as for v7: eighths / quarters of the tiles >= dp_tiles) on v7's sub-tile kernels behind it
+      // on the same stream (walkers = 0: every workgroup of that launch is a tail workgroup)
+      const int tail_wgs = (int)grid.x - g.walkers;
+      dim3 gmain(g.dp_tiles, 1, nbatch);
+      int rc = mkg::launch_v9(g, d->a_red_major != 0, d->b_red_major != 0, gmain, st, f16);
+      if (rc == MK_OK && tail_wgs > 0) {
+        GemmArgs gt = g;
+        gt.walkers = 0;
+        rc = mkg::launch_v7(gt, d->a_red_major != 0, d->b_red_major != 0, dim3(tail_wgs, 1, nbatch), st, false, f16);
+      }
       mkp::end(prof, st);
       return rc;
     }

@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Generates macaw_llm_amd/csrc/gemm_v9_loop.inc: the hand-placed K loop of the 4-wave 256 x 256 x 64 GEMM
+(gemm_v9.hip) as ONE inline-asm statement per operand layout.
+
+Why a generator: the loop is 64 MFMAs per K-tile with every other instruction (fragment reads, LDS-DMA pieces and
+their M0 writes, slot arithmetic, address updates) assigned to a specific MFMA gap -- hipcc cannot be steered to
+that (gemm_v8: 38-39 cycles per MFMA against 32.4 for a hand-placed stream, MI355X_MICROARCH.md "one wave per
+SIMD").  The placement rule lives HERE (function `kstep`), the output is committed next to the
+kernel and `tests/test_v9_gen_cpu.py` checks that the committed file is what this script writes and that the
+addressing identities the asm relies on hold against the C++ formulas of gemm_lds_image.inc.
+
+Register map of the asm block (fixed physical registers, all in the clobber list):
+  a[0:255]   accumulators, fragment (i, j) at a[(4 i + j) * 16 ...]           (i: A fragment row, j: B fragment)
+  v[0:15]    A fragments set 0      v[16:31] B fragments set 0
+  v[32:47]   A fragments set 1      v[48:63] B fragments set 1
+  v[64:71]   LDS-DMA voffsets of A  [h][i]       v[72:79] of B
+  v[80:83]   LDS read addresses of A (K-major: per k-step; reduction-major: per fragment), v[84:87] of B
+  s64 aoff (A slot of tile T: 0 / 32 Ki / 64 Ki)   s65 boff (0 / 32 Ki)   s66 kA2   s67 kB2 (K-tile byte offsets of T + 2)
+  s68 loop counter   s69 M0 base of the current piece group   s70 a1off   s71 a2off   s72 bnext   s73 dA   s74 dB   s75 kB1
+"""
+import sys
+
+HALF = 16384
+SLOT = 32768
+B_BASE = 3 * SLOT
+
+FA = [[0, 32][s] for s in range(2)]      # first VGPR of A fragments, set s
+FB = [[16, 48][s] for s in range(2)]
+VOA, VOB, ADA, ADB = 64, 72, 80, 84
+
+
+class Emit:
+    def __init__(self):
+        self.lines = []
+
+    def __call__(self, s):
+        self.lines.append(s)
+
+
+def frag_reads(red, set_base, addr_base, ks):
+    """instructions that read the 4 fragments of k-step `ks` of one operand into the register set at set_base"""
+    out = []
+    for f in range(4):
+        r = set_base + 4 * f
+        if not red:
+            off = f * 4096
+            out.append(f"ds_read_b128 v[{r}:{r + 3}], v{addr_base + ks}" + (f" offset:{off}" if off else ""))
+        else:
+            off = ks * 4096
+            out.append(f"ds_read_b64_tr_b16 v[{r}:{r + 1}], v{addr_base + f}" + (f" offset:{off}" if off else ""))
+            out.append(f"ds_read_b64_tr_b16 v[{r + 2}:{r + 3}], v{addr_base + f} offset:{off + 1024}")
+    return out
+
+
+def reads_of_kstep(a_red, b_red, s, ks):
+    """fragment reads of k-step ks into set s, in the order the MFMAs consume them (j outer, i inner:
+    B0, A0..A3, B1, B2, B3)"""
+    ra = frag_reads(a_red, FA[s], ADA, ks)
+    rb = frag_reads(b_red, FB[s], ADB, ks)
+    na, nb = (2 if a_red else 1), (2 if b_red else 1)
+    return rb[:nb] + ra + rb[nb:]
+
+
+def mfmas(s, first_zero=False):
+    out = []
+    for j in range(4):
+        for i in range(4):
+            acc = (4 * i + j) * 16
+            c = "0" if first_zero else f"a[{acc}:{acc + 15}]"
+            out.append(f"v_mfma_f32_32x32x16_@SFX@ a[{acc}:{acc + 15}], v[{FB[s] + 4 * j}:{FB[s] + 4 * j + 3}], "
+                       f"v[{FA[s] + 4 * i}:{FA[s] + 4 * i + 3}], {c}")
+    return out
+
+
+def kstep(e, mset, reads, dma, salu, valu):
+    """one k-step: 16 MFMAs on register set `mset`; the fillers by gap (gap g follows MFMA g):
+       reads (<= 24)  : gaps 0 .. 7 (one per gap) -- or two / three per gap when an operand is reduction-major
+       dma (0 or 4)   : the M0 write in gaps 8 / 10 / 12 / 14, the buffer_load ... lds in gaps 9 / 11 / 13 / 15
+       salu, valu     : one entry per gap, SALU in gaps 0 .. 7 (instructions that communicate through SCC are ONE
+                        entry and stay adjacent), VALU from gap 8 on
+    At most 4 entries follow any MFMA (the budget of a lone wave is ~5 issues per 32-cycle gap)."""
+    gaps = [[] for _ in range(16)]
+    per = (len(reads) + 7) // 8 if reads else 0
+    for k, r in enumerate(reads):
+        gaps[k // per].append(r)
+    for k, (m0w, ld) in enumerate(dma):
+        gaps[8 + 2 * k].append(m0w)
+        gaps[9 + 2 * k].append(ld)
+    assert len(salu) <= 8
+    for g, ins in enumerate(salu):          # gap g <- entry g: everything a piece group needs is formed by gap 7
+        gaps[g].append(ins)
+    g = 8 if reads else 0
+    for ins in valu:
+        gaps[g].append(ins)
+        g += 1
+    ms = mfmas(mset)
+    e("s_waitcnt lgkmcnt(0)")
+    for k in range(16):
+        e(ms[k])
+        for ins in gaps[k]:
+            for part in ins.split(" ; "):
+                e(part)
+        assert len(gaps[k]) <= 4, (k, gaps[k])
+
+
+def dma_group(op, dst_expr_sgpr, vo_base, soff):
+    """4 pieces: (M0 write, load).  s69 holds the LDS address of piece 0; pieces are 4 KiB apart."""
+    rs = "%[rsA]" if op == "A" else "%[rsB]"
+    out = []
+    for i in range(4):
+        m0w = f"s_add_u32 m0, s69, {i * 4096}" if i else "s_mov_b32 m0, s69"
+        out.append((m0w, f"buffer_load_dwordx4 v{vo_base + i}, {rs}, {soff} offen lds"))
+    return out
+
+
+def body(e, a_red, b_red, mode):
+    """one K-tile T.  mode FULL: tiles T + 1 and T + 2 exist; NEXT: T + 1 only; LAST: neither."""
+    nxt = mode != "LAST"
+    full = mode == "FULL"
+    # ---- k-step 0: MFMA set 0, reads k-step 1 -> set 1, LDS-DMA B(T + 1) half 1
+    salu = []
+    if nxt:
+        salu += ["s_add_u32 s70, s64, 0x8000 ; s_cmp_eq_u32 s70, 0x18000 ; s_cselect_b32 s70, 0, s70",
+                 "s_xor_b32 s72, s65, 0x8000",
+                 "s_sub_u32 s75, s67, %[stB]",
+                 "s_add_u32 s69, %[wv], s72",
+                 f"s_add_u32 s69, s69, {B_BASE + HALF}",
+                 "s_sub_u32 s73, s70, s64",
+                 "s_sub_u32 s74, s72, s65"]
+    if full:
+        salu += ["s_sub_u32 s71, s64, 0x8000 ; s_cmp_eq_u32 s64, 0 ; s_cselect_b32 s71, 0x10000, s71"]
+    kstep(e, 0, reads_of_kstep(a_red, b_red, 1, 1), dma_group("B", None, VOB + 4, "s75") if nxt else [], salu, [])
+    # ---- k-step 1: MFMA set 1, reads k-step 2 -> set 0, LDS-DMA A(T + 2) half 0
+    if full:
+        e("s_add_u32 s69, %[wv], s71")
+    kstep(e, 1, reads_of_kstep(a_red, b_red, 0, 2), dma_group("A", None, VOA, "s66") if full else [], [], [])
+    # ---- k-step 2: MFMA set 0, reads k-step 3 -> set 1, LDS-DMA A(T + 2) half 1; then the read addresses move
+    # to tile T + 1 (every address register had its last use for tile T in this k-step's reads)
+    if full:
+        e(f"s_add_u32 s69, s69, {HALF}")
+    valu = []
+    if nxt:
+        valu = [f"v_add_u32 v{ADA + k}, s73, v{ADA + k}" for k in range(4)] + \
+               [f"v_add_u32 v{ADB + k}, s74, v{ADB + k}" for k in range(4)]
+    kstep(e, 0, reads_of_kstep(a_red, b_red, 1, 3), dma_group("A", None, VOA + 4, "s66") if full else [], [], valu)
+    # ---- the one barrier of the tile: this wave's pieces of tile T + 1 have landed (everything older than the
+    # eight A(T + 2) pieces), its reads of tile T are complete
+    if nxt:
+        e("s_waitcnt vmcnt(8) lgkmcnt(0)" if full else "s_waitcnt vmcnt(0) lgkmcnt(0)")
+        e("s_barrier")
+        e("s_add_u32 s69, %[wv], s65")
+        e(f"s_add_u32 s69, s69, {B_BASE}")
+    # ---- k-step 3: MFMA set 1, reads k-step 0 of tile T + 1 -> set 0, LDS-DMA B(T + 2) half 0 into B(T)'s slot
+    salu = []
+    if nxt:
+        salu = ["s_mov_b32 s64, s70", "s_mov_b32 s65, s72", "s_add_u32 s66, s66, %[stA]", "s_add_u32 s67, s67, %[stB]"]
+        # (s65 is overwritten only after the M0 base of this k-step's pieces was formed above; s67 only after the
+        #  last piece has been issued: see the order check in `order_ok`)
+    kstep3(e, a_red, b_red, nxt, full, salu)
+
+
+def kstep3(e, a_red, b_red, nxt, full, salu):
+    reads = reads_of_kstep(a_red, b_red, 0, 0) if nxt else []
+    dma = dma_group("B", None, VOB, "s67") if full else []
+    gaps = [[] for _ in range(16)]
+    per = (len(reads) + 7) // 8 if reads else 0
+    for k, r in enumerate(reads):
+        gaps[k // per].append(r)
+    for k, (m0w, ld) in enumerate(dma):
+        gaps[8 + 2 * k].append(m0w)
+        gaps[9 + 2 * k].append(ld)
+    # bookkeeping: s64 / s65 early, the K-tile offsets behind the last piece (gap 15 reads s67)
+    if salu:
+        gaps[0].append(salu[0])
+        gaps[1].append(salu[1])
+        gaps[15].append(salu[2])
+        gaps[15].append(salu[3])
+    ms = mfmas(1)
+    e("s_waitcnt lgkmcnt(0)")
+    for k in range(16):
+        e(ms[k])
+        for ins in gaps[k]:
+            e(ins)
+        assert len(gaps[k]) <= 4
+
+
+def prologue(e, a_red, b_red):
+    e(f"v_mov_b32 v{VOA}, %[voA]")
+    e(f"v_mov_b32 v{VOB}, %[voB]")
+    for op, vo, red in (("A", VOA, a_red), ("B", VOB, b_red)):
+        st = f"%[i{op}]"
+        for i in range(1, 4):
+            e(f"v_add_u32 v{vo + i}, {st}, v{vo + i - 1}")
+        if not red:                       # h = 1: 128 rows further = four piece strides
+            e(f"v_add_u32 v{vo + 4}, {st}, v{vo + 3}")
+            for i in range(1, 4):
+                e(f"v_add_u32 v{vo + 4 + i}, {st}, v{vo + 3 + i}")
+        else:                             # h = 1: 128 columns further = 256 bytes
+            for i in range(4):
+                e(f"v_add_u32 v{vo + 4 + i}, 0x100, v{vo + i}")
+    for op, ad, red in (("A", ADA, a_red), ("B", ADB, b_red)):
+        e(f"v_mov_b32 v{ad}, %[ad{op}]")
+        sh = 6 if red else 5
+        for k in range(1, 4):
+            e(f"v_xor_b32 v{ad + k}, {hex(k << sh)}, v{ad}")
+    e("s_mov_b32 s64, 0")
+    e("s_mov_b32 s65, 0")
+    e("s_lshl_b32 s66, %[stA], 1")
+    e("s_lshl_b32 s67, %[stB], 1")
+    e("s_sub_u32 s68, %[nk], 2")
+    for r in range(256):
+        e(f"v_accvgpr_write_b32 a{r}, 0")
+    e("s_waitcnt vmcnt(12)")
+    e("s_barrier")
+    for r in reads_of_kstep(a_red, b_red, 0, 0):
+        e(r)
+
+
+def loop_text(a_red, b_red):
+    e = Emit()
+    prologue(e, a_red, b_red)
+    e("s_cmp_eq_u32 s68, 0")
+    e("s_cbranch_scc1 .Lv9n%=")
+    e(".p2align 6")
+    e(".Lv9l%=:")
+    body(e, a_red, b_red, "FULL")
+    e("s_sub_u32 s68, s68, 1")
+    e("s_cmp_lg_u32 s68, 0")
+    e("s_cbranch_scc1 .Lv9l%=")
+    e(".Lv9n%=:")
+    body(e, a_red, b_red, "NEXT")
+    body(e, a_red, b_red, "LAST")
+    e("s_nop 15")
+    e("s_nop 15")
+    return e.lines
+
+
+def order_ok(lines):
+    """static checks of the emitted stream: (1) every LDS-DMA is preceded by an M0 write with exactly one
+    instruction (the wait state) or more in between and no other M0 write after it; (2) SCC producer / consumer
+    pairs are adjacent; (3) no s_add / s_sub between s_cmp and s_cselect / s_cbranch"""
+    last_m0 = None
+    for n, l in enumerate(lines):
+        if " m0," in l:
+            last_m0 = n
+        if "buffer_load" in l:
+            assert last_m0 is not None and n - last_m0 >= 2, (n, l)
+            last_m0 = None if False else last_m0
+        if l.startswith("s_cselect") or l.startswith("s_cbranch_scc"):
+            assert lines[n - 1].startswith("s_cmp"), (n, lines[n - 1], l)
+    return True
+
+
+def c_string(lines):
+    out = []
+    for l in lines:
+        if "@SFX@" in l:
+            a, b = l.split("@SFX@")
+            out.append(f'  "{a}" MK_V9_SFX "{b}\\n\\t"')
+        else:
+            out.append(f'  "{l}\\n\\t"')
+    return " \\\n".join(out)
+
+
+def acc_read_macros():
+    """the epilogue's side: fragment (i, j) out of the accumulator file, 16 registers per statement"""
+    out = []
+    for i in range(4):
+        for j in range(4):
+            base = (4 * i + j) * 16
+            txt = "".join(f"v_accvgpr_read_b32 %{e}, a{base + e}\\n\\t" for e in range(16))
+            outs = ", ".join(f'"=v"((X)[{e}])' for e in range(16))
+            out.append(f"#define V9_ACC_READ_{i}_{j}(X) asm volatile(\"{txt}\" : {outs})")
+    return "\n".join(out)
+
+
+def main(path):
+    parts = ["// GENERATED by scripts/gen_v9_loop.py -- do not edit (tests/test_v9_gen_cpu.py compares).",
+             "// The K loop of gemm_v9 as inline asm, one string per operand layout; MK_V9_SFX = \"bf16\" / \"f16\".",
+             "// Register map and placement rule: see the generator."]
+    for a_red in (0, 1):
+        for b_red in (0, 1):
+            lines = loop_text(bool(a_red), bool(b_red))
+            order_ok(lines)
+            parts.append(f"#define V9_LOOP_TEXT_{a_red}{b_red} \\\n" + c_string(lines))
+    clob = ", ".join([f'"v{r}"' for r in range(88)] + [f'"a{r}"' for r in range(256)] +
+                     [f'"s{r}"' for r in range(64, 76)] + ['"scc"', '"memory"'])
+    parts.append(f"#define V9_LOOP_CLOBBERS {clob}")
+    parts.append(acc_read_macros())
+    txt = "\n".join(parts) + "\n"
+    if path == "-":
+        sys.stdout.write(txt)
+    else:
+        with open(path, "w") as f:
+            f.write(txt)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "macaw_llm_amd/csrc/gemm_v9_loop.inc")

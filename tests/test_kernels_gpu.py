@@ -164,6 +164,73 @@ def test_gemm_v8_one_wave_per_simd_kernel(dev, dtype, a_red, b_red, M, N, K):
     assert torch.equal(outs[14][:, :N], outs[11][:, :N])
 
 
+@pytest.mark.parametrize("dtype", H16)
+@pytest.mark.parametrize("a_red,b_red", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 128), (4096, 4096, 192), (4096, 4096, 256), (4096, 4096, 64 * 7),
+                                   (4608, 4096, 1024), (4096, 4352, 64 * 9)])
+def test_gemm_v9_hand_placed_k_loop(dev, dtype, a_red, b_red, M, N, K):
+    """gemm_v9.hip: the 4-wave 256 x 256 kernel whose K loop is one generated inline-asm statement
+    (scripts/gen_v9_loop.py; slot / wait protocol simulated on CPU in tests/test_v9_gen_cpu.py).  Whole tiles only,
+    at least one full round of 256: nk = 2, 3, 4, 7, 9, 16 (peeled first tile / zero, one, many trips of the
+    steady-state body / penultimate / last tile; the three-slot A ring and the two-slot B ring wrap), 288 and 272
+    tiles (the spatial tail goes to v7's sub-tile kernels in a second launch), every operand layout, bf16 and fp16
+    -- against torch fp32 matmul on the same 16-bit inputs and BIT-IDENTICAL to v7 (same MFMA, same k order per
+    output element), twice in a row (no state left behind in LDS / registers by the previous launch)."""
+    from macaw_llm_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + 3 * N + K + 9)
+    A = _rand((K, M) if a_red else (M, K), dtype, g)
+    B = _rand((K, N) if b_red else (N, K), dtype, g, 0.1)
+    Ad, Bd = A.to(dev), B.to(dev)
+    ref = ((Ad.float().t() if a_red else Ad.float()) @ (Bd.float() if b_red else Bd.float().t())).cpu()
+    outs = {}
+    try:
+        for cfg in (15, 11, 15):
+            lib.mk_gemm_set_cfg(cfg)
+            C = torch.full((M, N), float("nan"), dtype=dtype, device=dev)
+            ops.gemm_raw(Ad, Bd, C, M, N, K, Ad.stride(0), Bd.stride(0), N, a_red=a_red, b_red=b_red)
+            if cfg == 15 and 15 in outs:
+                assert torch.equal(C, outs[15]), "v9 not reproducible run to run"
+            outs[cfg] = C
+    finally:
+        lib.mk_gemm_set_cfg(-1)
+    _close(outs[15], ref, dtype, scale=0.1 * math.sqrt(K), what=f"v9 {M}x{N}x{K} {a_red}{b_red}")
+    assert torch.equal(outs[15], outs[11])
+
+
+def test_gemm_v9_epilogue_and_fallback(dev):
+    """bias + GELU + residual + accumulate through v9's row-by-row epilogue out of the accumulator file; a ragged
+    problem forced to cfg 15 is computed by v7 (whole tiles only) and stays correct."""
+    from macaw_llm_amd import lib as L
+    lib = L.load()
+    for M, N, K in ((4096, 4096, 256), (4000, 4100, 200)):
+        g = torch.Generator().manual_seed(7)
+        ld = (K + 7) // 8 * 8
+        A = torch.zeros((M, ld), dtype=torch.bfloat16)
+        A[:, :K] = _rand((M, K), torch.bfloat16, g)
+        B = torch.zeros((N, ld), dtype=torch.bfloat16)
+        B[:, :K] = _rand((N, K), torch.bfloat16, g, 0.1)
+        A, B = A.to(dev), B.to(dev)
+        bias = _rand((N,), torch.bfloat16, g).to(dev)
+        ldc = (N + 7) // 8 * 8
+        R = _rand((M, ldc), torch.bfloat16, g).to(dev)
+        outs = {}
+        try:
+            for cfg in (15, 5):
+                lib.mk_gemm_set_cfg(cfg)
+                C = torch.ones((M, ldc), dtype=torch.bfloat16, device=dev)
+                ops.gemm_raw(A, B, C, M, N, K, ld, ld, ldc, bias=bias, bias_mode=1, act=1, R=R, ldr=ldc, accumulate=True,
+                             alpha=0.5)
+                outs[cfg] = C
+        finally:
+            lib.mk_gemm_set_cfg(-1)
+        ref = torch.nn.functional.gelu(0.5 * (A[:, :K].float() @ B[:, :K].float().t()) + bias.float()) \
+            + R[:, :N].float() + 1.0
+        _close(outs[15][:, :N], ref.cpu(), torch.bfloat16, scale=2.0, what=f"v9 epilogue {M}x{N}x{K}")
+        d = (outs[15][:, :N].float() - outs[5][:, :N].float()).abs().max().item()
+        assert d <= 2 ** -6 * ref.abs().max().item() + 1e-6
+
+
 def test_gemm_v8_epilogue(dev):
     """bias + GELU + residual + accumulate through the 4 x 4-fragment LDS-transposed epilogue of v8."""
     from macaw_llm_amd import lib as L
