@@ -368,7 +368,19 @@ int pick_cfg(const mk_gemm_desc* d, int nbatch, bool v7_ok, int n_cus) {
       t2 += 4.0 + 0.65 * sp;
     }
   }
-  return t7 * 0.95 < t2 ? 11 : MK_GEMM_DEFAULT_CFG;   // (ties go to v7: the model is pessimistic for it)
+  if (!(t7 * 0.95 < t2)) return MK_GEMM_DEFAULT_CFG;   // (ties go to v7: the model is pessimistic for it)
+  // v9 (gemm_v9.hip: one wave per SIMD, hand-placed K loop, register epilogue): whole tiles, at least one full round,
+  // a plain epilogue.  Measured against v7 on cold operands (profiles/r05_gemm_v9_step_cold.csv): reduction-major x
+  // reduction-major (grad-weight) +2 ... +8 % on every step shape; inside the cfg-3 step (r05_gemm_v9_instep.txt)
+  // grad-weight +3 ... +6 %, grad-input (K-major x reduction-major) +0.5 ... +2.3 %, forward (both K-major) -1.5 %
+  // at K <= 12288 (v9's fixed cost per tile is 14 us against 12.5, its K-tile 1.485 us against 1.54).
+  // MK_GEMM_V9: 0 = never, 1 = this policy (default), 2 = wherever it is legal.
+  static const int v9_mode = [] { const char* e = getenv("MK_GEMM_V9"); return e ? atoi(e) : 1; }();
+  const bool v9_legal = d->dtype != MK_F32 && d->dtype != MK_FP8 && d->M % 256 == 0 && d->N % 256 == 0 && d->K % 64 == 0 &&
+                        full >= 1 && d->bias_mode == 0 && d->act == 0 && !d->R && !d->accumulate && !d->scale_a &&
+                        !d->scale_b;
+  if (v9_legal && (v9_mode == 2 || (v9_mode == 1 && (layout == 3 || layout == 1 || nk >= 256)))) return 15;
+  return 11;
 }
 }  // namespace
 
@@ -510,6 +522,10 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     g.ws = nullptr;
     g.counters = nullptr;
     g.ablate = 0;
+    {   // A/B switch of gemm_v9's epilogue (MK_V9_LDS_EPI=1: the LDS-transposed form also for plain products)
+      static const int v9_lds_epi = getenv("MK_V9_LDS_EPI") ? 1 : 0;
+      if (cfg == 15 && v9_lds_epi) g.ablate = 9;
+    }
     g.tail8 = 0;
     // resident workgroups per CU of the chosen kernel
     const int slots = n_cus * (t256 ? 1 : (cfg == 7 ? 4 : 2));
@@ -574,6 +590,13 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
       // on the same stream (walkers = 0: every workgroup of that launch is a tail workgroup)
       const int tail_wgs = (int)grid.x - g.walkers;
       dim3 gmain(g.dp_tiles, 1, nbatch);
+      // whole rounds of tiles and a register epilogue: one WALKING workgroup per planned CU (tile, tile + n_cus, ...),
+      // which requests its next tile's first K-tiles before the epilogue of the current one (gemm_v9_impl.inc)
+      static const bool no_walk9 = getenv("MK_GEMM_NO_WALK") != nullptr;
+      const bool plain9 = d->bias_mode == 0 && d->act == 0 && !d->R && !d->accumulate && g.c_vec == 2 && !d->scale_a &&
+                          !d->scale_b && g.ablate != 9;
+      if (!no_walk9 && plain9 && nbatch == 1 && n_cus % 8 == 0 && g.dp_tiles > n_cus && g.dp_tiles % n_cus == 0)
+        gmain.x = n_cus;
       int rc = mkg::launch_v9(g, d->a_red_major != 0, d->b_red_major != 0, gmain, st, f16);
       if (rc == MK_OK && tail_wgs > 0) {
         GemmArgs gt = g;

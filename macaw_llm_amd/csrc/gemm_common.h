@@ -317,7 +317,11 @@ MK_DEV void wave_epilogue16(const f32x16 (&acc)[FM][FN], const GemmArgs& g, ET* 
           e16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (ET)v[e];
+#ifdef MK_EPI_NOSTORE   // timing-only experiment builds: the value is formed, the store is not issued
+          asm volatile("" :: "v"(o));
+#else
           *reinterpret_cast<e16x8*>(C + (long)m * g.ldc + ncol) = o;
+#endif
         }
       }
     } else {

@@ -20,6 +20,9 @@ Register map of the asm block (fixed physical registers, all in the clobber list
 """
 import sys
 
+# timing-only ablations for experiment builds (scripts/probe/build_v9_variants.sh); the shipped text has none set
+NO_DMA = NO_READ = NO_BAR = False
+
 HALF = 16384
 SLOT = 32768
 B_BASE = 3 * SLOT
@@ -80,6 +83,10 @@ def kstep(e, mset, reads, dma, salu, valu):
                         entry and stay adjacent), VALU from gap 8 on
     At most 4 entries follow any MFMA (the budget of a lone wave is ~5 issues per 32-cycle gap)."""
     gaps = [[] for _ in range(16)]
+    if NO_READ:
+        reads = []
+    if NO_DMA:
+        dma = []
     per = (len(reads) + 7) // 8 if reads else 0
     for k, r in enumerate(reads):
         gaps[k // per].append(r)
@@ -147,7 +154,8 @@ def body(e, a_red, b_red, mode):
     # eight A(T + 2) pieces), its reads of tile T are complete
     if nxt:
         e("s_waitcnt vmcnt(8) lgkmcnt(0)" if full else "s_waitcnt vmcnt(0) lgkmcnt(0)")
-        e("s_barrier")
+        if not NO_BAR:
+            e("s_barrier")
         e("s_add_u32 s69, %[wv], s65")
         e(f"s_add_u32 s69, s69, {B_BASE}")
     # ---- k-step 3: MFMA set 1, reads k-step 0 of tile T + 1 -> set 0, LDS-DMA B(T + 2) half 0 into B(T)'s slot
@@ -160,8 +168,8 @@ def body(e, a_red, b_red, mode):
 
 
 def kstep3(e, a_red, b_red, nxt, full, salu):
-    reads = reads_of_kstep(a_red, b_red, 0, 0) if nxt else []
-    dma = dma_group("B", None, VOB, "s67") if full else []
+    reads = reads_of_kstep(a_red, b_red, 0, 0) if (nxt and not NO_READ) else []
+    dma = dma_group("B", None, VOB, "s67") if (full and not NO_DMA) else []
     gaps = [[] for _ in range(16)]
     per = (len(reads) + 7) // 8 if reads else 0
     for k, r in enumerate(reads):
@@ -184,7 +192,7 @@ def kstep3(e, a_red, b_red, nxt, full, salu):
         assert len(gaps[k]) <= 4
 
 
-def prologue(e, a_red, b_red):
+def prologue(e, a_red, b_red, walk=False):
     e(f"v_mov_b32 v{VOA}, %[voA]")
     e(f"v_mov_b32 v{VOB}, %[voB]")
     for op, vo, red in (("A", VOA, a_red), ("B", VOB, b_red)):
@@ -210,15 +218,18 @@ def prologue(e, a_red, b_red):
     e("s_sub_u32 s68, %[nk], 2")
     for r in range(256):
         e(f"v_accvgpr_write_b32 a{r}, 0")
-    e("s_waitcnt vmcnt(12)")
+    # a walking workgroup's later tiles: the epilogue stores of the previous tile are still in flight behind the
+    # requests of this one, and loads and stores share the counter without a guaranteed order between them --
+    # only vmcnt(0) says "tile 0 has landed" there (it waits for A(1) / B(1) half 0 and the stores as well)
+    e("s_waitcnt vmcnt(0)" if walk else "s_waitcnt vmcnt(12)")
     e("s_barrier")
     for r in reads_of_kstep(a_red, b_red, 0, 0):
         e(r)
 
 
-def loop_text(a_red, b_red):
+def loop_text(a_red, b_red, walk=False):
     e = Emit()
-    prologue(e, a_red, b_red)
+    prologue(e, a_red, b_red, walk)
     e("s_cmp_eq_u32 s68, 0")
     e("s_cbranch_scc1 .Lv9n%=")
     e(".p2align 6")
@@ -280,9 +291,10 @@ def main(path):
              "// Register map and placement rule: see the generator."]
     for a_red in (0, 1):
         for b_red in (0, 1):
-            lines = loop_text(bool(a_red), bool(b_red))
-            order_ok(lines)
-            parts.append(f"#define V9_LOOP_TEXT_{a_red}{b_red} \\\n" + c_string(lines))
+            for walk in (False, True):
+                lines = loop_text(bool(a_red), bool(b_red), walk)
+                order_ok(lines)
+                parts.append(f"#define V9_LOOP_TEXT_{a_red}{b_red}{'_W' if walk else ''} \\\n" + c_string(lines))
     clob = ", ".join([f'"v{r}"' for r in range(88)] + [f'"a{r}"' for r in range(256)] +
                      [f'"s{r}"' for r in range(64, 76)] + ['"scc"', '"memory"'])
     parts.append(f"#define V9_LOOP_CLOBBERS {clob}")
@@ -296,4 +308,14 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "macaw_llm_amd/csrc/gemm_v9_loop.inc")
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    for a in sys.argv[1:]:
+        if a == "--nodma":
+            NO_DMA = True
+        elif a == "--noread":
+            NO_READ = True
+        elif a == "--nobar":
+            NO_BAR = True
+        elif a.startswith("--"):
+            sys.exit(f"unknown option {a}")
+    main(args[0] if args else "macaw_llm_amd/csrc/gemm_v9_loop.inc")

@@ -167,7 +167,8 @@ def test_gemm_v8_one_wave_per_simd_kernel(dev, dtype, a_red, b_red, M, N, K):
 @pytest.mark.parametrize("dtype", H16)
 @pytest.mark.parametrize("a_red,b_red", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(4096, 4096, 128), (4096, 4096, 192), (4096, 4096, 256), (4096, 4096, 64 * 7),
-                                   (4608, 4096, 1024), (4096, 4352, 64 * 9)])
+                                   (4608, 4096, 1024), (4096, 4352, 64 * 9),
+                                   (8192, 4096, 256), (6144, 8192, 192)])   # 2 and 3 whole rounds: walking workgroups
 def test_gemm_v9_hand_placed_k_loop(dev, dtype, a_red, b_red, M, N, K):
     """gemm_v9.hip: the 4-wave 256 x 256 kernel whose K loop is one generated inline-asm statement
     (scripts/gen_v9_loop.py; slot / wait protocol simulated on CPU in tests/test_v9_gen_cpu.py).  Whole tiles only,

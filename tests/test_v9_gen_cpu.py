@@ -262,9 +262,9 @@ class Sim:
         return lo[1][:4]
 
 
-def _lines(a_red, b_red):
+def _lines(a_red, b_red, walk=False):
     out = []
-    for l in gen.loop_text(a_red, b_red):
+    for l in gen.loop_text(a_red, b_red, walk):
         for k, v in (("%[stA]", None), ("%[stB]", None)):
             pass
         out.append(l.replace("@SFX@", "bf16").replace("%=", "X"))
@@ -274,14 +274,15 @@ def _lines(a_red, b_red):
 @pytest.mark.parametrize("a_red,b_red", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("nk", [2, 3, 4, 5, 8, 9])
 @pytest.mark.parametrize("w", [0, 1, 2, 3])
-def test_simulated_stream_is_consistent(a_red, b_red, nk, w):
+@pytest.mark.parametrize("walk", [False, True])
+def test_simulated_stream_is_consistent(a_red, b_red, nk, w, walk):
     sim = Sim(a_red, b_red, nk, w)
     wr, wc = w >> 1, w & 1                       # this wave reads A half wr and B half wc
     sub = {"%[stA]": str(sim.stA), "%[stB]": str(sim.stB), "%[nk]": str(nk), "%[wv]": str(w * 1024),
            "%[iA]": "1000000", "%[iB]": "2000000", "%[voA]": "0", "%[voB]": "0", "%[adA]": str(wr * HALF),
            "%[adB]": str(B_BASE + wc * HALF), "%[rsB]": "RSB", "%[rsA]": "RSA"}
     lines = []
-    for l in _lines(a_red, b_red):
+    for l in _lines(a_red, b_red, walk):
         for k, v in sub.items():
             l = l.replace(k, v)
         lines.append(l)
