@@ -404,6 +404,10 @@ def main():
     for i in range(args.steps):
         last = i == args.steps - 1
         if last:
+            # the per-kernel figures (`roofline`) come from THIS step: it updates behind the backward in one launch, so
+            # that no kernel of another stream runs beside the GEMMs and a launch's duration is its own (the other
+            # steps overlap the per-bucket AdamW launches with the backward on one rank: BucketedStep.local_overlap)
+            runtime.serial_update = True
             ops.prof_begin()
             runtime.profile_comm(True)
         loss = step(eager=last)
@@ -462,9 +466,17 @@ def main():
                        "setup_steps": 1, "activation_checkpointing": bool(spec["ckpt"]),
                        "peak_mem_gib": round(peak_mem, 1),
                        "loss": round(float(loss.detach()), 4)},
-            "roofline": {"bound": "mfma", "kernel": "all mk_gemm launches of the step: gemm_bf16_v7_kernel (256x256, "
+            "roofline": {"bound": "mfma", "kernel": "all mk_gemm launches of the step: gemm_bf16_v7_kernel (256x256, 8 waves, "
                                                     "csrc/gemm_v7.hip; its <.., FP8> instantiation for e4m3 operands) + "
+                                                    "gemm_bf16_v9_kernel (256x256, 4 waves, generated inline-asm K loop, "
+                                                    "csrc/gemm_v9.hip: grad-weight and grad-input) + "
                                                     "gemm_bf16_v2_kernel (128x128, csrc/gemm.hip)",
+                         "measured_on": ("the LAST timed step, HIP events around every launch on the compute stream; that "
+                                         "step updates behind the backward in one AdamW launch, so no kernel of another "
+                                         "stream runs beside the GEMMs"
+                                         + (" (the other timed steps overlap the per-bucket AdamW launches with the "
+                                            "backward on a high-priority side stream)"
+                                            if getattr(runtime, "local_overlap", False) else "")),
                          "achieved": round(achieved / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(gemm_frac, 4),
                          "traffic": traffic,

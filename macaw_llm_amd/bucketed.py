@@ -200,7 +200,8 @@ def _zero_(t):
 
 
 class _Bucket:
-    __slots__ = ("idx", "w", "g", "shard_g", "items", "n", "arrived", "launched", "ready", "rs", "seen", "dirty")
+    __slots__ = ("idx", "w", "g", "shard_g", "items", "n", "arrived", "launched", "ready", "rs", "seen", "dirty",
+                 "updated")
 
     def __init__(self, idx):
         self.idx = idx
@@ -210,6 +211,7 @@ class _Bucket:
         self.launched = False
         self.ready = False
         self.rs = None
+        self.updated = False   # its AdamW launch went out behind the backward (one rank, local_overlap)
         self.seen = set()      # ids of the parameters that received a gradient in this window
         self.dirty = set()     # ids whose gradient slot may be non-zero (written since it was zeroed)
 
@@ -222,7 +224,8 @@ class BucketedStep:
                  max_grad_norm: Optional[float] = None, overlap: bool = True,
                  force_collectives: bool = False, direct_grads: bool = True, model=None,
                  zero1: bool = True, average_accumulated: bool = True,
-                 loss_scaler: Optional[DynamicLossScaler] = None, comm_cus: int = 0):
+                 loss_scaler: Optional[DynamicLossScaler] = None, comm_cus: int = 0,
+                 local_overlap: Optional[bool] = None):
         if model is not None:
             # fuse q|k|v / gate|up BEFORE the parameters are pinned into buckets (the lazy fusion at
             # the first forward must never re-home a bucket view: round-2 advisor finding)
@@ -250,6 +253,8 @@ class BucketedStep:
         self.overlap = overlap
         self.direct_grads = direct_grads
         self.dev_hyper = False         # True while train.GraphedStep captures: AdamW scalars from device memory
+        self.serial_update = False     # True: this window updates behind the backward (one launch) even with local_overlap
+        self._local_live = False
         self.grad_scale = 1.0          # multiplied into every gradient inside AdamW (set to 1 / loss_scale for
                                        # fp16 training with a scaled loss; set it before the backward)
         self.grad_norm = None          # device scalar (fp32) of the last clipped step
@@ -266,8 +271,25 @@ class BucketedStep:
         self._cursor = 0
         self._arrival: List[int] = []
         dev = self.params[0].device
-        self.side = (torch.cuda.Stream(device=dev)
-                     if (dev.type == "cuda" and overlap and self.collective) else None)
+        # ONE rank, no collectives (opt-in: local_overlap=True / MACAW_LOCAL_OVERLAP=1): the AdamW launch of a bucket goes
+        # out on a HIGH-PRIORITY side stream (another pool of hardware queues: see overlap_group()) as soon as the
+        # bucket's gradients are complete, instead of as one launch behind the backward (34 ms = 15 % of the cfg-3 step).
+        # MEASURED and therefore OFF by default (profiles/r05_local_overlap_ab.txt, two alternations on one box):
+        # 231.5 / 232.3 ms per step overlapped against 229.5 / 230.1 serial -- AdamW is HBM-bound at 5.6 TB/s and takes
+        # every CU a finishing GEMM workgroup frees, so the backward's GEMMs lose what the tail gains; the holes a
+        # 288-tile GEMM leaves are too short for it.  (With N ranks the same launches update 1/N of a bucket each and
+        # the question does not arise.)  Same kernels, same arithmetic, same optimizer-state keys either way
+        # (bit-identical weights: tests/test_train_gpu.py).
+        import os as _os
+        if local_overlap is None:
+            local_overlap = bool(_os.environ.get("MACAW_LOCAL_OVERLAP"))
+        self.local_overlap = bool(local_overlap and overlap and not self.collective and dev.type == "cuda")
+        if dev.type == "cuda" and overlap and self.collective:
+            self.side = torch.cuda.Stream(device=dev)
+        elif self.local_overlap:
+            self.side = torch.cuda.Stream(device=dev, priority=-1)
+        else:
+            self.side = None
         self._build(bucket_bytes)
         self._gathers = []
         self._comm = None              # communication profile of the step in flight (profile_comm())
@@ -415,9 +437,13 @@ class BucketedStep:
             self._check_homes()
             for b in self.buckets:
                 b.arrived, b.launched, b.ready, b.rs = 0, False, False, None
+                b.updated = False
                 b.seen = set()
             self._cursor = 0
             self._arrival = []
+            # (the updates go out behind the backward, on the side stream, unless this window is being captured in a
+            #  hipGraph or profiled kernel by kernel: `serial_update`)
+            self._local_live = self.local_overlap and not self.dev_hyper and not self.serial_update
         else:
             for b in self.buckets:
                 b.arrived = 0
@@ -477,6 +503,11 @@ class BucketedStep:
     def _launch(self, b: _Bucket):
         b.launched = True
         if not self.collective:
+            if self.local_overlap and self._local_live and not self._needs_global():
+                self.side.wait_stream(torch.cuda.current_stream())      # the bucket's gradients are complete
+                with torch.cuda.stream(self.side):
+                    self._finish_bucket(b, self._acc_scale())
+                b.updated = True
             return
         self._reserve_cus(True)
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
@@ -602,8 +633,13 @@ class BucketedStep:
                     if b.rs is not None and b.rs[0] is not None:
                         b.rs[0].wait()
             elif not self.collective and hasattr(self.opt, "step_buckets") and self.buckets[0].w.is_cuda:
-                self.opt.step_buckets([((b.idx, 0, b.n), b.w, b.g) for b in self.buckets], scale,
-                                      dev_hyper=self.dev_hyper)
+                rest = [b for b in self.buckets if not getattr(b, "updated", False)]
+                if len(rest) == len(self.buckets):
+                    self.opt.step_buckets([((b.idx, 0, b.n), b.w, b.g) for b in self.buckets], scale,
+                                          dev_hyper=self.dev_hyper)
+                else:
+                    for b in rest:                 # (buckets whose gradients completed in finish(): zeros / stragglers)
+                        self._finish_bucket(b, scale)
             else:
                 for i in self._order:
                     self._finish_bucket(self.buckets[i], scale)
@@ -736,7 +772,8 @@ class BucketedStep:
         nb = len(self.buckets)
         mb = sum(b.n * b.w.element_size() for b in self.buckets) / 2 ** 20
         if not self.collective:
-            mode = "local (one fused AdamW launch)"
+            mode = ("local (per-bucket AdamW launches behind the backward on a high-priority side stream)"
+                    if self.local_overlap and not self._needs_global() else "local (one fused AdamW launch)")
         elif self.zero1:
             mode = "ZeRO-1 reduce-scatter / shard AdamW / all-gather"
         else:

@@ -545,3 +545,22 @@ def test_optimizer_state_dict_resumes_bit_exactly(dev):
         for n, p in B.named_parameters():
             assert torch.equal(p.detach(), want[n]), (warm, n)
         rt_b.remove()
+
+
+def test_one_rank_updates_overlap_the_backward_and_change_no_bit(dev):
+    """round 5 (opt-in, measured +-0 at 7B and therefore off by default): with one rank and no collectives the AdamW
+    launch of a bucket can go out on a high-priority side stream as soon as the bucket's gradients are complete (from
+    the second step on: the first discovers the order) instead of as one launch behind the backward.  Same kernel,
+    same keys: the weights and the optimizer state are bit-identical to the serial form."""
+    fx = load_case("micro_all")
+    cfg = configs.get(fx["config_name"])
+    l_ser, p_ser, rt_ser = _run_bucketed(dev, fx, cfg, 4)
+    l_ovl, p_ovl, rt_ovl = _run_bucketed(dev, fx, cfg, 4, local_overlap=True)
+    assert rt_ovl.local_overlap and rt_ovl.side is not None and not rt_ser.local_overlap and rt_ser.side is None
+    assert any(b.updated for b in rt_ovl.buckets), "no bucket was updated behind the backward"
+    assert not any(getattr(b, "updated", False) for b in rt_ser.buckets)
+    assert l_ovl == l_ser
+    for n in p_ser:
+        assert torch.equal(p_ovl[n], p_ser[n]), n
+    assert sorted(map(str, rt_ovl.opt.state)) == sorted(map(str, rt_ser.opt.state))
+    assert "side stream" in rt_ovl.describe() and "one fused AdamW launch" in rt_ser.describe()
