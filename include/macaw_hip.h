@@ -96,9 +96,13 @@ typedef struct mk_gemm_desc {
 #define MK_GEMM_B_KPAD_ZERO 2
 int mk_gemm(const mk_gemm_desc* d, void* stream);
 /* Tuning / A-B hook: force the bf16 kernel configuration of the following mk_gemm calls
- * (11 = 256x256 v7, 14 = 256x256 v8 with one wave per SIMD, 5 = 128x128 v2, 7 = v2 BK32, 0 = generic; -1 = automatic).  A forced
- * configuration is still replaced where it is not legal for the problem. */
+ * (11 = 256x256 v7 with eight waves, 15 = 256x256 v9: four waves, one per SIMD, hand-placed inline-asm K loop (whole tiles
+ * only), 14 = its hipcc-scheduled predecessor v8 (experiment builds only), 5 = 128x128 v2, 7 = v2 BK32, 0 = generic;
+ * -1 = automatic).  A forced configuration is still replaced where it is not legal for the problem.
+ * Replaces cuBLAS behind nn.Linear of /root/reference/modeling.py:134-140,159-162,597. */
 int mk_gemm_set_cfg(int cfg);
+/* 1 if kernel configuration `cfg` is compiled into this library (14 only with MK_EXPERIMENTS=1 at build time). */
+int mk_gemm_has_cfg(int cfg);
 /* How many CUs the tile kernels may plan for (0 = all of the device, the default).  The 256x256 kernels hold one
  * workgroup per CU with all of its LDS, so a CU occupied by another resident kernel -- an RCCL channel of the
  * gradient reduce-scatter running beside the backward (train.sh:14, configs/deepspeed_config.json:22-41) -- is

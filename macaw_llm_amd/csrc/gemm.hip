@@ -282,12 +282,21 @@ int skinny32_cfg(int N) {
 // tuning / A-B hook (scripts/gemm_bench.cpp, tests): force a kernel configuration for the
 // following mk_gemm calls of this process (-1 = automatic choice); same meaning as MK_GEMM_CFG
 extern "C" int mk_gemm_set_cfg(int cfg) { g_force_cfg = cfg; return MK_OK; }
+// 1 if the kernel configuration is compiled into this library (experiment kernels: build.py MK_EXPERIMENTS)
+extern "C" int mk_gemm_has_cfg(int cfg) {
+#ifdef MK_WITH_V8
+  if (cfg == 14) return 1;
+#endif
+  return cfg == 0 || cfg == 5 || cfg == 7 || cfg == 11 || cfg == 15;
+}
 namespace { int g_plan_cus = 0; }
 extern "C" int mk_gemm_set_cus(int n) { const int prev = g_plan_cus; g_plan_cus = n > 0 ? n : 0; return prev; }
 
 namespace mkg {
 int launch_v7(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st, bool fp8, bool f16);  // gemm_v7.hip
+#ifdef MK_WITH_V8   // experiment builds only (build.py MK_EXPERIMENTS=1)
 int launch_v8(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st, bool f16);            // gemm_v8.hip
+#endif
 int launch_v9(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st, bool f16);            // gemm_v9.hip
 }
 
@@ -485,6 +494,9 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     if (env_cfg >= 0) cfg = env_cfg;
     else cfg = pick_cfg(d, nbatch, v7_ok, n_cus);
     if (fp8 && cfg != 11) cfg = 5;        // fp8 exists on the two LDS-DMA tile kernels only
+#ifndef MK_WITH_V8
+    if (cfg == 14) cfg = 11;              // gemm_v8 is not part of the shipped library (build.py MK_EXPERIMENTS)
+#endif
     if ((cfg == 11 || cfg == 14 || cfg == 15) && !v7_ok) cfg = 5;
     if ((cfg == 14 || cfg == 15) && fp8) cfg = 11;       // (v8 / v9 have no e4m3 instantiation)
     // v9 (hand-placed K loop, gemm_v9.hip) takes whole 256 x 256 x 64 tiles only
@@ -579,11 +591,13 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
         g.walkers = n_cus;
       }
     }
+#ifdef MK_WITH_V8
     if (v8) {
       const int rc = mkg::launch_v8(g, d->a_red_major != 0, d->b_red_major != 0, grid, st, f16);
       mkp::end(prof, st);
       return rc;
     }
+#endif
     if (v9 && g.dp_tiles >= n_cus) {
       // whole tiles [0, dp_tiles) on v9, one workgroup each; the spatial tail of the last partial round (planned
       // above exactly as for v7: eighths / quarters of the tiles >= dp_tiles) on v7's sub-tile kernels behind it

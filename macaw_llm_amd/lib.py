@@ -54,6 +54,7 @@ SIGNATURES = {
     "mk_abi_version": [],
     "mk_gemm": [C.POINTER(GemmDesc), _vp],
     "mk_gemm_set_cfg": [_i32],
+    "mk_gemm_has_cfg": [_i32],
     "mk_gemm_set_cus": [_i32],
     "mk_prof_begin": [],
     "mk_prof_end": [_vp, _vp, _vp],

@@ -59,10 +59,25 @@ def test_the_one_wave_per_simd_gemm_keeps_its_accumulators_in_registers(ks):
     """v8: 256 accumulator registers (AGPRs) + fragments / addresses in the other half of the 512-entry file, no
     spill and NO scratch: with LLVM's default `#pragma unroll` budget the 4 x 4-fragment epilogue stays rolled,
     indexes the accumulators dynamically and the whole tile goes through scratch (build.FILE_FLAGS)."""
-    found = _pick(ks, "_v8_kernel<")
+    found = {k: v for k, v in ks.items() if "_v8_kernel<" in k}
+    if not found:
+        pytest.skip("gemm_v8 is an experiment kernel (MK_EXPERIMENTS=1); its successor is pinned below")
     assert len(found) == 8                                  # 4 layouts x {bf16, f16}
     for k, v in found.items():
         assert 256 < v["vgpr_count"] <= 512, (k, v)         # (the note counts VGPRs + AGPRs of the unified file)
+        assert v.get("vgpr_spill_count", 0) == 0 and v.get("private_segment_fixed_size", 0) == 0, (k, v)
+        assert v["max_flat_workgroup_size"] == 256, (k, v)
+
+
+def test_the_hand_placed_gemm_owns_the_accumulator_file_and_nothing_spills(ks):
+    """v9: the asm block owns a[0:255] (256 AGPRs) and v[0:87]; the compiler's code around it must stay inside the
+    arch VGPRs it has left (<= 256 in all, so that it never parks a value in an AGPR the asm block is using), without
+    spills or scratch, one wave per SIMD."""
+    found = _pick(ks, "_v9_kernel<")
+    assert len(found) == 8                                  # 4 layouts x {bf16, f16}
+    for k, v in found.items():
+        assert v.get("agpr_count", 256) == 256, (k, v)
+        assert 256 + 88 <= v["vgpr_count"] <= 512, (k, v)   # (the note counts VGPRs + AGPRs of the unified file)
         assert v.get("vgpr_spill_count", 0) == 0 and v.get("private_segment_fixed_size", 0) == 0, (k, v)
         assert v["max_flat_workgroup_size"] == 256, (k, v)
 
