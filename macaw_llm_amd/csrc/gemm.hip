@@ -267,7 +267,7 @@ namespace { int g_force_cfg = -1; }
 namespace {
 // kernel for 17 ... 32 token rows: 19 = two 16-token tiles per 16 weight rows (gemm_skinny16_kernel MT = 2: N / 16
 // workgroups), 22 = 32 x 32 pipelined (gemm_skinny32p_kernel: N / 32 workgroups, ONE token byte from L2 per weight
-// byte instead of two).  Measured cold (scripts/gemm_shapes_decode32.txt, profiles/r03_decode32_cold.csv): 22
+// byte instead of two).  Measured cold (scripts/gemm_shapes_decode32.txt, profiles/archive/r03_decode32_cold.csv): 22
 // wins where N / 32 still fills the chip (N = 22016: 52 vs 69 us, 32007: 73 vs 91, 12288: 35 vs 37), 19 where it
 // does not (N = 4096 = 128 workgroups: 14.5 vs 18.2 us at K = 4096, 33.6 vs 46.2 at K = 11008).
 // MK_GEMM_SKINNY32 forces one (read per call: scripts/bench_generate.py switches it in-process).

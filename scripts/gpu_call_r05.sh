@@ -41,21 +41,32 @@ for step in "$@"; do
     tests)
       timeout 1500 python -m pytest tests -m gpu -q -rf --timeout 300 --durations=12 -p no:cacheprovider > $out/tests.log 2>&1
       echo "pytest rc=$?" >> $out/tests.log ;;
-    v9)      # the hand-placed 4-wave K loop: parity vs v7 in the harness (cfg 15 checks against cfg 11), K-slope, step shapes
-      GB_CHECK=1 GB_ITERS=3 GB_ROUNDS=1 timeout 300 $GB scripts/gemm_shapes_v9_check.txt > $out/v9_check.csv 2> $out/v9_check.err
+    v9)      # gemm_v9 in the harness: checked against the fp32 reference rows, K-slope and cold step shapes beside v7 / vendor
+      GB_ITERS=3 GB_ROUNDS=1 timeout 300 $GB scripts/gemm_shapes_v9_check.txt > $out/v9_check.csv 2> $out/v9_check.err
       for i in 1 2; do GB_ITERS=10 GB_ROUNDS=3 timeout 200 $GB scripts/gemm_shapes_v9_kslope.txt > $out/v9_kslope_$i.csv 2>> $out/v9.err; done
-      GB_COLD=1 GB_ITERS=10 GB_ROUNDS=3 timeout 400 $GB scripts/gemm_shapes_v9_step.txt > $out/v9_step_cold.csv 2>> $out/v9.err ;;
-    v9pmc)   # cycles, not seconds: v7 / v8 / v9 / vendor on one cube
-      printf '8192 8192 8192 0 11 14 15 100\n' > /tmp/pmc_shape.txt
-      (cd /tmp && GB_ITERS=3 GB_ROUNDS=1 timeout 120 rocprofv3 \
-         --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
-         -d /tmp/pmc9 -o p --output-format csv -- $OLDPWD/$GB /tmp/pmc_shape.txt > $OLDPWD/$out/v9_pmc.log 2>&1)
-      f=$(find /tmp/pmc9 -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp $f $out/v9_pmc.csv
-      (cd /tmp && GB_ITERS=3 GB_ROUNDS=1 timeout 120 rocprofv3 --kernel-trace -d /tmp/kt9 -o k --output-format csv \
-         -- $OLDPWD/$GB /tmp/pmc_shape.txt > $OLDPWD/$out/v9_kt.log 2>&1)
-      f=$(find /tmp/kt9 -name '*kernel_trace.csv' | head -1); [ -n "$f" ] && cp $f $out/v9_kt.csv ;;
-    attn)
-      timeout 200 python scripts/bench_attn.py > $out/attn.txt 2>&1 ;;
+      GB_COLD=1 GB_ITERS=10 GB_ROUNDS=3 timeout 400 $GB scripts/gemm_shapes_v9_step.txt > $out/v9_step_cold.csv 2>> $out/v9.err
+      timeout 900 python -m pytest tests/test_kernels_gpu.py -k "v9" -q -rf -x --timeout 300 -p no:cacheprovider > $out/t_v9.log 2>&1
+      echo "pytest rc=$?" >> $out/t_v9.log ;;
+    v9pmc)   # cycles, not seconds: v7 / v8 / v9 / vendor and v9's timing-only ablations (scripts/probe/build_v9_variants.sh first)
+      bash scripts/probe/v9_pmc_ablate.sh $out ${V9VARS:-nodma noread nodma_noread nobar} > $out/v9_pmc_summary.txt 2>&1 ;;
+    v9mode)  # in-step A/B of the kernel policy: MK_GEMM_V9 = 0 (v7 only) / 1 (policy) / 2 (v9 wherever legal), alternated
+      for i in 1 2; do for m in 0 1 2; do
+        MK_GEMM_V9=$m MACAW_GEMM_REPORT=$out/shapes_v9mode${m}_$i.csv timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline \
+          > $out/bench_v9mode${m}_$i.json 2> $out/bench_v9mode${m}_$i.err
+      done; done ;;
+    attn)    # attention micro-benchmark, the attention tests, PMC of the S = 2048 kernels
+      timeout 300 python scripts/bench_attn.py > $out/attn.txt 2>&1
+      MK_ATTN_DQ_ASYNC=1 timeout 300 python scripts/bench_attn.py > $out/attn_dqasync.txt 2>&1
+      timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -k "attn or attention or flash or forward_backward" -q -x --timeout 300 -p no:cacheprovider > $out/t_attn.log 2>&1
+      echo "pytest rc=$?" >> $out/t_attn.log
+      bash scripts/probe/attn_pmc.sh ${tag}_pmc > $out/attn_pmc_summary.txt 2>&1 ;;
+    localov) # one rank: per-bucket AdamW behind the backward (opt-in) against the one fused launch, alternated
+      for i in 1 2; do
+        timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_serial_$i.json 2> $out/bench_serial_$i.err
+        MACAW_LOCAL_OVERLAP=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_overlap_$i.json 2> $out/bench_overlap_$i.err
+      done ;;
+    overlap2) # the collective path on one rank, default group vs the high-priority group, comm_cus 0 / 8 / 16 / 32
+      bash scripts/probe/overlap_1rank_r05.sh > $out/overlap2.log 2>&1 ;;
     *) echo "unknown step $step" ;;
   esac
   echo "$step: $(( $(date +%s) - t0 )) s" >> $out/timing.txt
