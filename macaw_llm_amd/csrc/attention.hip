@@ -27,6 +27,7 @@
 #define MK_E16_T _Float16
 #define MK_E16_NS e_f16
 #define flash_fwd_kernel flash_fwd_f16_kernel
+#define flash_fwd8_kernel flash_fwd8_f16_kernel
 #define flash_bwd_prep_kernel flash_bwd_prep_f16_kernel
 #define flash_bwd_dq_kernel flash_bwd_dq_f16_kernel
 #define flash_bwd_dkv_kernel flash_bwd_dkv_f16_kernel
@@ -34,6 +35,7 @@
 #define flash_fwd_short_kernel flash_fwd_short_f16_kernel
 #include "attention_impl.inc"
 #undef flash_fwd_kernel
+#undef flash_fwd8_kernel
 #undef flash_bwd_prep_kernel
 #undef flash_bwd_dq_kernel
 #undef flash_bwd_dkv_kernel

@@ -67,6 +67,16 @@ for step in "$@"; do
       done ;;
     overlap2) # the collective path on one rank, default group vs the high-priority group, comm_cus 0 / 8 / 16 / 32
       bash scripts/probe/overlap_1rank_r05.sh > $out/overlap2.log 2>&1 ;;
+    attn8)   # the 8-wave forward: its own tests first (a failure or a hang switches the kernel off for the rest of the call),
+             # then the micro-benchmark with both forward kernels alternated in one process
+      timeout 240 python -m pytest tests/test_kernels_gpu.py -k "eight_wave or lazy_rescale" -q -rf -x --timeout 200 -p no:cacheprovider > $out/t_attn8.log 2>&1
+      rc=$?; echo "pytest rc=$rc" >> $out/t_attn8.log
+      if [ $rc -ne 0 ]; then export MK_ATTN_FWD8_MIN=0; echo "fwd8 OFF for the rest of the call" >> $out/t_attn8.log; fi
+      timeout 300 python scripts/bench_attn.py > $out/attn8.txt 2>&1 ;;
+    bench2s) # cfg 2 with the per-shape GEMM report (the table was never committed)
+      MACAW_GEMM_REPORT=$out/gemm_shapes_per_step_cfg2.csv timeout 600 python bench.py --config 2 --steps 8 --warmup 3 --no-cpu-baseline > $out/bench_cfg2.json 2> $out/bench_cfg2.err ;;
+    gen)     # generate(): B = 1 / 8 / 16 / 32 from ONE run
+      timeout 600 python scripts/bench_generate.py 1 8 16 32 > $out/generate.txt 2>&1 ;;
     *) echo "unknown step $step" ;;
   esac
   echo "$step: $(( $(date +%s) - t0 )) s" >> $out/timing.txt

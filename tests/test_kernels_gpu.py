@@ -680,6 +680,64 @@ def test_flash_attention_fwd(dev, dtype, hd, Lq, Lk, causal, masked):
     torch.testing.assert_close(lse.cpu(), torch.logsumexp(s, -1), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("hd,Lq,Lk,causal,masked", [
+    (128, 1024, 1024, True, True),       # whole 256-row blocks, padded tail
+    (128, 1100, 1100, True, False),      # ragged last block: waves without rows still stage and count barriers
+    (128, 1030, 1500, False, True),      # non-causal, Lk not a multiple of the 64-key tile
+    (128, 1200, 1030, True, False),      # Lk < Lq: the first rows see no key at all (exact zeros, lse = -inf)
+    (128, 1030, 1300, True, False),      # Lk > Lq: every row sees a prefix of Lk - Lq extra keys
+    (64, 1500, 1500, False, False),      # head_dim 64 instantiation (Whisper's shape)
+    (64, 1100, 1100, True, True),
+])
+@pytest.mark.parametrize("dtype", H16)
+def test_flash_attention_fwd_eight_wave_kernel(dev, dtype, hd, Lq, Lk, causal, masked, monkeypatch):
+    """flash_fwd8_kernel (256 query rows per workgroup, waves 4-7 one segment behind waves 0-3, P V of tile t - 1 in
+    the matrix segment of tile t, 2-deep K / V rings) against fp32 softmax(scale QK^T + mask) V on the same inputs.
+    B H = 6 (b, h) pairs x 5-6 blocks; the 4-wave kernel on the same inputs must agree to output rounding."""
+    monkeypatch.setenv("MK_ATTN_FWD8_MIN", "1024")
+    monkeypatch.setenv("MK_ATTN_FWD8_HD64", "1")
+    g = torch.Generator().manual_seed(Lq * 7 + Lk + hd)
+    Bn, H = 2, 3
+    D = H * hd
+    q, k, v = (_rand((Bn * L, D), dtype, g) for L in (Lq, Lk, Lk))
+    kmask = torch.ones(Bn, Lk, dtype=torch.int32)
+    if masked:
+        kmask[1, -77:] = 0
+        kmask[0, 100:130] = 0
+    scale = hd ** -0.5
+
+    def run():
+        o = torch.full((Bn * Lq, D), 3.0, dtype=dtype, device=dev)
+        lse = torch.full((Bn, H, Lq), 5.0, dtype=torch.float32, device=dev)
+        ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), o, Bn, H, Lq, Lk, hd, D, Lq * D, D, Lk * D,
+                           D, Lk * D, D, Lq * D, scale, kmask=kmask.to(dev) if masked else None,
+                           causal=causal, lse=lse)
+        torch.cuda.synchronize()
+        return o, lse
+
+    o8, lse8 = run()
+    monkeypatch.setenv("MK_ATTN_FWD8_MIN", "0")
+    o4, lse4 = run()
+    qf = q.float().view(Bn, Lq, H, hd).transpose(1, 2)
+    kf = k.float().view(Bn, Lk, H, hd).transpose(1, 2)
+    vf = v.float().view(Bn, Lk, H, hd).transpose(1, 2)
+    s = qf @ kf.transpose(-1, -2) * scale
+    if causal:
+        i = torch.arange(Lq)[:, None]
+        j = torch.arange(Lk)[None, :]
+        s = s.masked_fill(j > i + (Lk - Lq), float("-inf"))
+    if masked:
+        s = s.masked_fill(kmask[:, None, None, :] == 0, float("-inf"))
+    p = torch.softmax(s, -1)
+    p = torch.where(torch.isnan(p), torch.zeros_like(p), p)        # rows without a visible key: zeros
+    ref = (p @ vf).transpose(1, 2).reshape(Bn * Lq, D)
+    _close(o8, ref, dtype, what="flash fwd8")
+    _close(o4, ref, dtype, what="flash fwd (4-wave)")
+    ref_lse = torch.logsumexp(s, -1)
+    torch.testing.assert_close(lse8.cpu(), ref_lse, rtol=1e-4, atol=2e-4)
+    assert (o8.float() - o4.float()).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 4e-3)
+
+
 def test_flash_attention_fwd_lazy_rescale_branches_at_seq_2048(dev):
     """cdna_hip_programming.md rule 26: the lazy rescale (attention forward keeps a row's running
     maximum until it grows by more than 2^DEFER) is a data-dependent branch that bounded random
