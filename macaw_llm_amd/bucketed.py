@@ -293,6 +293,7 @@ class BucketedStep:
         self._build(bucket_bytes)
         self._gathers = []
         self._comm = None              # communication profile of the step in flight (profile_comm())
+        self.digests = None            # trace_digests(): per step and bucket, sha1 of each stage of the update
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     # ------------------------------------------------------------------ layout ---
@@ -656,8 +657,43 @@ class BucketedStep:
             self._comm["ev1"] = torch.cuda.Event(enable_timing=True)
             self._comm["ev1"].record()          # the step is complete on the compute stream
         ops.bump_weight_version()               # cached fp8 copies of the weights are stale now
+        if self.digests is not None:
+            self._record_digests()
         if getattr(self.opt, "_loaded_keys", None) is not None and not self.last_step_skipped:
             self.opt.assert_restored()          # every checkpoint entry found its slot (else: wrong layout)
+
+    # ------------------------------------------------------------ diagnosis ---
+    def trace_digests(self, on: bool = True):
+        """DEBUGGING aid (synchronises and copies every bucket to the host each step): after every completed step
+        `self.digests` gains one entry per bucket -- sha1 of (a) the LOCAL gradient bucket as the backward left it,
+        (b) this rank's reduced slice (behind the reduce-scatter / all-reduce), (c) the bucket after AdamW and the
+        all-gather.  Two runs that should be bit-identical are compared stage by stage: the first stage that differs
+        names the culprit -- (a) a backward kernel of one of the bucket's parameters, (b) the collective, (c) the
+        optimizer kernel or the gather (tests/test_train_gpu.py prints this on a replica / runtime mismatch)."""
+        self.digests = [] if on else None
+
+    def _record_digests(self):
+        import hashlib
+
+        def dg(t):
+            return hashlib.sha1(t.detach().contiguous().view(torch.uint8).cpu().numpy().tobytes()).hexdigest()[:16]
+
+        if self.params[0].is_cuda:
+            torch.cuda.synchronize()
+        step = len(self.digests)
+        entry = []
+        for b in self.buckets:
+            lo, n = self._shard(b)
+            red = b.shard_g if (self.collective and self.zero1) else b.g[lo:lo + n]
+            entry.append({"step": step, "bucket": b.idx, "elements": b.n, "owned": (lo, n),
+                          "local_grad": dg(b.g) if (self.collective and self.zero1) else None,
+                          "reduced": dg(red), "updated": dg(b.w)})
+        self.digests.append(entry)
+
+    def bucket_of(self, named_params) -> dict:
+        """parameter name -> bucket index (for messages), given `model.named_parameters()`"""
+        where = {id(p): b.idx for b in self.buckets for p, _, _ in b.items}
+        return {n: where[id(p)] for n, p in named_params if id(p) in where}
 
     def _clip_scale(self, acc_scale: float):
         """the global statistic of a step: with `max_grad_norm`,

@@ -77,6 +77,11 @@ for step in "$@"; do
       MACAW_GEMM_REPORT=$out/gemm_shapes_per_step_cfg2.csv timeout 600 python bench.py --config 2 --steps 8 --warmup 3 --no-cpu-baseline > $out/bench_cfg2.json 2> $out/bench_cfg2.err ;;
     gen)     # generate(): B = 1 / 8 / 16 / 32 from ONE run
       timeout 600 python scripts/bench_generate.py 1 8 16 32 > $out/generate.txt 2>&1 ;;
+    tpins)   # the tightened bf16 generate() pin and the world-2 tests with the stage-digest diagnosis
+      timeout 900 python -m pytest tests/test_fullsize_gpu.py tests/test_train_gpu.py -k "generate_at_7b or two_ranks" -q -s -rf --timeout 600 -p no:cacheprovider > $out/t_pins.log 2>&1
+      echo "pytest rc=$?" >> $out/t_pins.log ;;
+    attnpmc) # PMC of the S = 2048 attention kernels (the 8-wave forward included)
+      bash scripts/probe/attn_pmc.sh ${tag}_pmc > $out/attn_pmc_summary.txt 2>&1 ;;
     *) echo "unknown step $step" ;;
   esac
   echo "$step: $(( $(date +%s) - t0 )) s" >> $out/timing.txt

