@@ -82,6 +82,21 @@ for step in "$@"; do
       echo "pytest rc=$?" >> $out/t_pins.log ;;
     attnpmc) # PMC of the S = 2048 attention kernels (the 8-wave forward included)
       bash scripts/probe/attn_pmc.sh ${tag}_pmc > $out/attn_pmc_summary.txt 2>&1 ;;
+    bench4ab) # cfg 4 in-step A/B of the forward attention kernels (4-wave vs 8-wave at S = 2048), alternated twice
+      for i in 1 2; do
+        MK_ATTN_FWD8_MIN=0 timeout 600 python bench.py --config 4 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_cfg4_fwd4_$i.json 2> $out/bench_cfg4_fwd4_$i.err
+        MK_ATTN_FWD8_MIN=1024 timeout 600 python bench.py --config 4 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_cfg4_fwd8_$i.json 2> $out/bench_cfg4_fwd8_$i.err
+      done
+      python - $out <<'PY'
+import json, sys, glob
+for f in sorted(glob.glob(sys.argv[1] + "/bench_cfg4_fwd*_?.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1]); r = d["roofline"]
+        print(f.split("/")[-1], d["value"], d["ms_per_step"], r["attention_fwd"], r["attention_bwd"])
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
+      ;;
     *) echo "unknown step $step" ;;
   esac
   echo "$step: $(( $(date +%s) - t0 )) s" >> $out/timing.txt
