@@ -37,7 +37,7 @@ if has prof || has prof3; then
     cd $ROOT
   done
 fi
-TRAFFIC_CFGS="3 2 4 5"
+TRAFFIC_CFGS=${TRAFFIC_CFGS:-"3 2 4 5"}
 has traffic3 && TRAFFIC_CFGS="3"
 if has traffic || has traffic3; then
   cd /tmp
