@@ -6,7 +6,9 @@
 // attention_impl.inc) has been the LLaMA layers' training path since round 1; only the fp32 parity engine keeps
 // the GEMM + softmax formulation.
 //
-// Work decomposition: block = 4 waves, each wave owns 32 query rows; the block walks the keys
+// Long sequences at head_dim 128 (Lq >= 1024, LLaMA at S = 2048): flash_fwd8_kernel -- 8 waves = 256 query rows per
+// workgroup, matrix and softmax segments of its two wave groups interleaved across barriers (attention_impl.inc).
+// Work decomposition of the 4-wave kernels: block = 4 waves, each wave owns 32 query rows; the block walks the keys
 // in tiles of 64 staged in LDS (K: [key][d] XOR-swizzled for ds_read_b128; V: [key][d] read
 // back TRANSPOSED with ds_read_b64_tr_b16).  Both products use v_mfma_f32_32x32x16_bf16 with
 // the operands swapped so that a lane owns ONE query column:
