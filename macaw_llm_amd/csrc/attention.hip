@@ -30,6 +30,7 @@
 #define MK_E16_NS e_f16
 #define flash_fwd_kernel flash_fwd_f16_kernel
 #define flash_fwd8_kernel flash_fwd8_f16_kernel
+#define flash_fwd4x64_kernel flash_fwd4x64_f16_kernel
 #define flash_bwd_prep_kernel flash_bwd_prep_f16_kernel
 #define flash_bwd_dq_kernel flash_bwd_dq_f16_kernel
 #define flash_bwd_dkv_kernel flash_bwd_dkv_f16_kernel
@@ -38,6 +39,7 @@
 #include "attention_impl.inc"
 #undef flash_fwd_kernel
 #undef flash_fwd8_kernel
+#undef flash_fwd4x64_kernel
 #undef flash_bwd_prep_kernel
 #undef flash_bwd_dq_kernel
 #undef flash_bwd_dkv_kernel

@@ -26,13 +26,12 @@ for name, B, H, S, hd, causal in SHAPES:
     fl = 4.0 * pairs * hd * B * H
     variants = [("fwd", fwd, 1.0, {}), ("bwd", bwd, 2.0, {})]
     if S >= 1024:       # A/B of the forward kernels in one process (the launcher reads the switches per call)
-        variants = [("fwd 4-wave", fwd, 1.0, {"MK_ATTN_FWD8_MIN": "0"}),
-                    ("fwd 8-wave", fwd, 1.0, {"MK_ATTN_FWD8_MIN": "1024", "MK_ATTN_FWD8_HD64": "1"}),
-                    ("fwd 4-wave", fwd, 1.0, {"MK_ATTN_FWD8_MIN": "0"}),
-                    ("fwd 8-wave", fwd, 1.0, {"MK_ATTN_FWD8_MIN": "1024", "MK_ATTN_FWD8_HD64": "1"}),
-                    ("bwd", bwd, 2.0, {})]
+        e4, e8 = {"MK_ATTN_FWD8_MIN": "0"}, {"MK_ATTN_FWD8_MIN": "1024", "MK_ATTN_FWD8_HD64": "1", "MK_ATTN_FWD4X64": "0"}
+        e464 = {"MK_ATTN_FWD8_MIN": "1024", "MK_ATTN_FWD4X64": "1"}
+        variants = [("fwd 4-wave", fwd, 1.0, e4), ("fwd 8-wave", fwd, 1.0, e8)] + ([("fwd 4x64", fwd, 1.0, e464)] if hd == 128 else [])
+        variants = variants + variants + [("bwd", bwd, 2.0, {})]
     for tag, fn, mult, env in variants:
-        for k_ in ("MK_ATTN_FWD8_MIN", "MK_ATTN_FWD8_HD64"):
+        for k_ in ("MK_ATTN_FWD8_MIN", "MK_ATTN_FWD8_HD64", "MK_ATTN_FWD4X64"):
             os.environ.pop(k_, None)
         os.environ.update(env)
         for _ in range(3): fn()

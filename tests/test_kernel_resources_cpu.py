@@ -93,7 +93,11 @@ def test_no_hot_kernel_spills(ks):
 
 def test_attention_and_streaming_kernels_keep_their_occupancy(ks):
     for k, v in _pick(ks, "flash_fwd").items():
-        assert v["vgpr_count"] <= 256, (k, v)              # two 4-wave workgroups per SIMD pair
+        if "flash_fwd4x64" in k:                           # one wave per SIMD by design: the whole 512-entry file, no scratch
+            assert 256 < v["vgpr_count"] <= 512 and v.get("private_segment_fixed_size", 0) == 0, (k, v)
+            assert v["max_flat_workgroup_size"] == 256, (k, v)
+            continue
+        assert v["vgpr_count"] <= 256, (k, v)              # two waves per SIMD (two 4-wave workgroups or one of 8 waves)
     for k, v in _pick(ks, "adamw_multi_kernel").items():
         assert v["vgpr_count"] <= 72, (k, v)               # HBM-bound: >= 7 waves per SIMD in flight
     for stem in ("gemm_skinny16_kernel", "gemm_skinny32p_kernel"):

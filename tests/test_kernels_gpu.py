@@ -715,7 +715,12 @@ def test_flash_attention_fwd_eight_wave_kernel(dev, dtype, hd, Lq, Lk, causal, m
         torch.cuda.synchronize()
         return o, lse
 
+    monkeypatch.setenv("MK_ATTN_FWD4X64", "0")
     o8, lse8 = run()
+    if hd == 128:                # the 4-wave x 64-row form (one wave per SIMD) of the same walk
+        monkeypatch.setenv("MK_ATTN_FWD4X64", "1")
+        o464, lse464 = run()
+        monkeypatch.setenv("MK_ATTN_FWD4X64", "0")
     monkeypatch.setenv("MK_ATTN_FWD8_MIN", "0")
     o4, lse4 = run()
     qf = q.float().view(Bn, Lq, H, hd).transpose(1, 2)
@@ -733,6 +738,9 @@ def test_flash_attention_fwd_eight_wave_kernel(dev, dtype, hd, Lq, Lk, causal, m
     ref = (p @ vf).transpose(1, 2).reshape(Bn * Lq, D)
     _close(o8, ref, dtype, what="flash fwd8")
     _close(o4, ref, dtype, what="flash fwd (4-wave)")
+    if hd == 128:
+        _close(o464, ref, dtype, what="flash fwd 4x64")
+        torch.testing.assert_close(lse464.cpu(), torch.logsumexp(s, -1), rtol=1e-4, atol=2e-4)
     ref_lse = torch.logsumexp(s, -1)
     torch.testing.assert_close(lse8.cpu(), ref_lse, rtol=1e-4, atol=2e-4)
     assert (o8.float() - o4.float()).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 4e-3)
