@@ -21,12 +21,13 @@ LIB = PKG / "libmacaw_hip.so"
 ARCH = "gfx950"
 # MK_EXPERIMENTS=1 also builds the kernels that lost their A/B and stay in the tree as measured experiments:
 # gemm_v8.hip (the 4-wave 256 x 256 GEMM scheduled by hipcc: superseded by gemm_v9's hand-placed loop; `mk_gemm_set_cfg(14)`
-# falls back to v7 without it, tests/test_kernels_gpu.py::test_gemm_v8_* skip)
+# falls back to v7 without it, tests/test_kernels_gpu.py::test_gemm_v8_* skip) and flash_fwd4x64_kernel (attention forward on one
+# wave per SIMD: loses to the 8-wave kernel, profiles/r05_attn8.txt F; MK_ATTN_FWD4X64=1 selects it in such a build)
 EXPERIMENTS = bool(os.environ.get("MK_EXPERIMENTS"))
 SOURCES = ["gemm.hip", "gemm_v7.hip", *(["gemm_v8.hip"] if EXPERIMENTS else []), "gemm_v9.hip", "norm.hip",
            "elementwise.hip", "softmax.hip", "attention.hip", "decode.hip", "preprocess.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", *os.environ.get("MK_EXTRA_FLAGS", "").split(),
-         *(["-DMK_WITH_V8"] if EXPERIMENTS else []), "-Wno-unused-result"]
+         *(["-DMK_WITH_V8", "-DMK_WITH_FWD4X64"] if EXPERIMENTS else []), "-Wno-unused-result"]
 
 
 # per-source flags.  gemm_v8.hip: the LDS-transposed epilogue of a 4 x 4-fragment wave tile exceeds LLVM's

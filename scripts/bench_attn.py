@@ -28,7 +28,7 @@ for name, B, H, S, hd, causal in SHAPES:
     if S >= 1024:       # A/B of the forward kernels in one process (the launcher reads the switches per call)
         e4, e8 = {"MK_ATTN_FWD8_MIN": "0"}, {"MK_ATTN_FWD8_MIN": "1024", "MK_ATTN_FWD8_HD64": "1", "MK_ATTN_FWD4X64": "0"}
         e464 = {"MK_ATTN_FWD8_MIN": "1024", "MK_ATTN_FWD4X64": "1"}
-        variants = [("fwd 4-wave", fwd, 1.0, e4), ("fwd 8-wave", fwd, 1.0, e8)] + ([("fwd 4x64", fwd, 1.0, e464)] if hd == 128 else [])
+        variants = [("fwd 4-wave", fwd, 1.0, e4), ("fwd 8-wave", fwd, 1.0, e8)] + ([("fwd 4x64", fwd, 1.0, e464)] if (hd == 128 and os.environ.get("MK_EXPERIMENTS")) else [])
         variants = variants + variants + [("bwd", bwd, 2.0, {})]
     for tag, fn, mult, env in variants:
         for k_ in ("MK_ATTN_FWD8_MIN", "MK_ATTN_FWD8_HD64", "MK_ATTN_FWD4X64"):
