@@ -70,7 +70,7 @@ CONFIGS = {
 METRIC = "multimodal samples/sec (img+audio+128 tok) fwd+bwd at 1/2/4/8 MI355X"
 
 
-def pmc_gemm_traffic(config: int):
+def pmc_gemm_traffic(config: int, mk_gemm_launches: int = 0):
     """(bytes, source file) -- HBM-side bytes per mk_gemm launch from the committed rocprofv3 --pmc
     passes of this same command FOR THIS CONFIGURATION (profiles/rNN_step_traffic_pmc[_cfgK].csv:
     FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE, separate passes, last
@@ -96,6 +96,10 @@ def pmc_gemm_traffic(config: int):
                     # the template argument list contains commas: the numeric columns are the last four
                     n += int(c[-4])
                     gb += float(c[-3]) + float(c[-2])
+        # per mk_gemm LAUNCH, like `achieved`: since round 5 one mk_gemm call may be two kernels (gemm_v9 for the whole
+        # tiles + the sub-tile kernel for the spatial tail), so the step's total is divided by the step's mk_gemm count
+        # when the caller knows it (the profiled step and the timed step are the same command); else by kernel launches
+        n = mk_gemm_launches if mk_gemm_launches > 0 else n
         return (round(gb * 1e9 / n), os.path.basename(path)) if n else (None, None)
     except (OSError, ValueError, IndexError):
         return None, None
@@ -430,7 +434,7 @@ def main():
     if rank == 0:
         S = spec["seq"]
         alg_tf = spec["alg_tf"]
-        traffic, traffic_src = pmc_gemm_traffic(args.config)
+        traffic, traffic_src = pmc_gemm_traffic(args.config, gemm_n + gemm8[2])
         # all mk_gemm launches: bf16 (kind 0) + fp8 (kind 3, cfg 5).  `frac` prices every launch against
         # ITS OWN dense peak (2.5 PFLOP/s bf16, 5 PFLOP/s e4m3 -- MI355X_MICROARCH.md:42-43): the time the
         # step's GEMM FLOPs would take at peak / the time they took.
