@@ -27,6 +27,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -247,6 +248,35 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("MACAW_CPU_THREADS", "64"))))
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch_command(n: int, argv: list, port: int | None = None) -> list:
+    """the command a bare `python bench.py --gpus N ...` re-executes itself through: one process per GPU on this
+    node, rendezvous on 127.0.0.1 (the container hostname may not resolve), same arguments"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or _free_port()),
+            os.path.abspath(__file__), *argv]
+
+
+# DESIGN.md section 6's prediction for the metric's configuration (cfg 3, 32 samples per GPU), so that the first
+# measured 1/2/4/8 curve can be read against it from the line alone.  N = 2 is ONE xGMI link between the pair
+# (2 x 6.7 GB per step over ~60 GB/s): expected to scale badly whatever the software does.
+PREDICTED_CFG3 = {
+    1: dict(step_ms=[220, 221], speedup=[1.0, 1.0], note="no collective; one fused AdamW launch behind the backward"),
+    2: dict(step_ms=[305, 325], speedup=[1.35, 1.45], rs_ag_ms_per_bucket=[6.7, 6.7],
+            note="link-bound: one xGMI link (7 links go to 7 different peers), the collectives outlast the backward"),
+    4: dict(step_ms=[230, 240], speedup=[3.7, 3.8], rs_ag_ms_per_bucket=[3.6, 3.6], note="3 links per GPU in use"),
+    8: dict(step_ms=[222, 270], speedup=[6.5, 7.9], rs_ag_ms_per_bucket=[2.0, 3.1],
+            note="222-230 ms if the collectives hide behind the backward as in the 1-rank overlap experiment "
+                 "(profiles/r05_overlap_1rank.txt), 270 ms if only half of them do"),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -267,11 +297,16 @@ def main():
                     "(the printed line is then marked invalid)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N` (how the driver invokes N = 1): start the N ranks ourselves, exactly as
+        # train.sh:13 does (torchrun --nnodes 1 --nproc_per_node N); rank 0's JSON line and the ranks' stderr pass
+        # straight through, the exit code is the launcher's
+        raise SystemExit(subprocess.call(self_launch_command(args.gpus, sys.argv[1:])))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     # MACAW_SHARE_GPU=1 + MACAW_DIST_BACKEND=gloo: N ranks on ONE GPU with gloo collectives -- how the
@@ -507,6 +542,14 @@ def main():
         # how the step's communication went on rank 0 (last timed step): the un-overlapped tail behind the backward
         # and every bucket's reduce-scatter / all-gather duration and bytes -- see BucketedStep.comm_report()
         line["comm"] = comm
+        if args.config == 3 and world in PREDICTED_CFG3 and B == CONFIGS[3]["batch"]:
+            pred = dict(PREDICTED_CFG3[world], source="DESIGN.md section 6 (model: RCCL ring bus bandwidth 230-350 GB/s at "
+                        "N = 8, ~170 at N = 4, ~60 at N = 2; 27 ms of step time per 100 ms of overlapped side work)")
+            if isinstance(line["comm"], dict):
+                line["comm"]["predicted"] = pred
+                line["comm"]["predicted_ms"] = pred["step_ms"]
+            else:
+                line["comm"] = {"world": world, "collective": "none", "predicted": pred, "predicted_ms": pred["step_ms"]}
         if args.layers is not None:
             line["invalid"] = f"debug run with --layers {args.layers}"
         if share_gpu or backend != "nccl" or inject is not None:

@@ -116,15 +116,21 @@ def overlap_group():
     import os
     if os.environ.get("MACAW_COMM_NORMAL_PRIORITY"):
         return None, "default process group (normal-priority stream: MACAW_COMM_NORMAL_PRIORITY)"
-    key = dist.get_world_size()
-    if key not in _OVERLAP_GROUP:
+    # NOTE dist.new_group() is a collective over the WORLD: every rank must construct its BucketedStep (with the same
+    # MACAW_COMM_NORMAL_PRIORITY) -- or pass process_group= explicitly.  The cache is keyed by the LIVE default group
+    # object: after destroy_process_group() / re-init in one process (tests, notebooks) a stale group is never handed out.
+    world = dist.distributed_c10d._get_default_group()
+    if _OVERLAP_GROUP.get("world") is not world:
+        _OVERLAP_GROUP.clear()
+        _OVERLAP_GROUP["world"] = world
         try:
             opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-            _OVERLAP_GROUP[key] = (dist.new_group(backend="nccl", pg_options=opts),
-                                   "own RCCL group on a high-priority stream")
-        except Exception as e:      # noqa: BLE001  (an older torch without the option: the default group works)
-            _OVERLAP_GROUP[key] = (None, f"default process group (no high-priority group: {e!r})"[:160])
-    return _OVERLAP_GROUP[key]
+        except (TypeError, AttributeError) as e:      # a torch without the option: the default group works
+            _OVERLAP_GROUP["group"] = (None, f"default process group (no high-priority option: {e!r})"[:160])
+        else:
+            _OVERLAP_GROUP["group"] = (dist.new_group(backend="nccl", pg_options=opts),
+                                       "own RCCL group on a high-priority stream")
+    return _OVERLAP_GROUP["group"]
 
 
 class DynamicLossScaler:
@@ -734,8 +740,11 @@ class BucketedStep:
     # ---------------------------------------------------------- checkpoint / resume ---
     def layout(self) -> dict:
         """what the optimizer's shard keys depend on: a checkpoint resumes only into the same layout"""
-        return {"world": self.world if self.collective else 1, "rank": self.rank if self.collective else 0,
-                "zero1": bool(self.zero1 and self.collective), "bucket_elems": [int(b.n) for b in self.buckets],
+        # the shard keys depend on the rank only under ZeRO-1; in all-reduce mode the state is REPLICATED (HF's stock
+        # save writes rank 0's file and every rank reloads it: ADVICE r5) -- rank 0 there
+        sharded = bool(self.zero1 and self.collective)
+        return {"world": self.world if self.collective else 1, "rank": self.rank if sharded else 0,
+                "zero1": sharded, "bucket_elems": [int(b.n) for b in self.buckets],
                 "dtypes": [str(b.w.dtype) for b in self.buckets]}
 
     def state_dict(self) -> dict:

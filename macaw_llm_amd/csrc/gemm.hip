@@ -500,7 +500,7 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     if ((cfg == 11 || cfg == 14 || cfg == 15) && !v7_ok) cfg = 5;
     if ((cfg == 14 || cfg == 15) && fp8) cfg = 11;       // (v8 / v9 have no e4m3 instantiation)
     // v9 (hand-placed K loop, gemm_v9.hip) takes whole 256 x 256 x 64 tiles only
-    if (cfg == 15 && (d->M % 256 != 0 || d->N % 256 != 0 || d->K % 64 != 0)) cfg = 11;
+    if (cfg == 15 && (d->M % 256 != 0 || d->N % 256 != 0 || d->K % 64 != 0 || d->K < 128)) cfg = 11;
     if (cfg != 0 && cfg != 5 && cfg != 7 && cfg != 11 && cfg != 14 && cfg != 15) cfg = 5;
     if (cfg >= 5 && !v2_ok) cfg = 0;
     if (fp8 && cfg != 5 && cfg != 11) return MK_ERR_UNSUPPORTED;
@@ -621,6 +621,9 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
       return rc;
     }
     if (t256) {
+      // cfg 15 with fewer whole tiles than planned CUs (forced via MK_GEMM_CFG / mk_gemm_set_cfg) runs on v7: the
+      // profile must say so
+      if (v9) mkp::set_cfg(prof, 11);
       const int rc = mkg::launch_v7(g, d->a_red_major != 0, d->b_red_major != 0, grid, st, fp8, f16);
       mkp::end(prof, st);
       return rc;

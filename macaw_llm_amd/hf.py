@@ -50,6 +50,13 @@ from .bucketed import BucketedStep, DynamicLossScaler, default_comm_cus
 from .optim import FusedAdamW
 
 # the channel cap has to be in the environment before RCCL builds its communicator (the first collective)
+if ("NCCL_MAX_NCHANNELS" not in os.environ and torch.distributed.is_available()
+        and torch.distributed.is_initialized()):
+    import warnings
+    warnings.warn("macaw_llm_amd.hf imported after init_process_group() without NCCL_MAX_NCHANNELS in the environment: "
+                  "if RCCL has already built its communicator the 16-channel cap set here does not apply and "
+                  "comm_cus (16 CUs left to the collectives) may not match the channels in use; export "
+                  "NCCL_MAX_NCHANNELS=16 in the launcher or pass macaw_comm_cus", stacklevel=2)
 os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
 
 
@@ -186,11 +193,17 @@ class MacawTrainerMixin:
             # HF's last window of an epoch may hold fewer micro-batches (Trainer._run_epoch)
             rt.accumulate_steps = max(1, int(getattr(self, "current_gradient_accumulation_steps",
                                                      self.args.gradient_accumulation_steps)))
-        rt.begin()
-        with self.compute_loss_context_manager():
-            loss = self.compute_loss(model, inputs)
-        rt.scale_loss(loss).backward()
-        rt.finish()
+        try:
+            rt.begin()
+            with self.compute_loss_context_manager():
+                loss = self.compute_loss(model, inputs)
+            rt.scale_loss(loss).backward()
+            rt.finish()
+        except BaseException:
+            # a window whose forward / backward raised at micro-step k > 0 must not leave _micro = k and the direct
+            # gradient destinations installed: the next begin() would accumulate onto stale bucket contents
+            rt.abort()
+            raise
         # the runtime averages the window inside AdamW; HF sums what training_step returns over the window
         return loss.detach() / rt.accumulate_steps
 

@@ -67,6 +67,30 @@ def kernels(lib=LIB):
     return {d.replace("(anonymous namespace)::", ""): out[n] for n, d in zip(names, dem)}
 
 
+def disassemble(substr, lib=LIB):
+    """{mangled symbol: [instruction lines]} for every function of the library whose mangled name contains `substr`
+    (llvm-objdump -d of the code objects that define such a symbol)"""
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for i, co in enumerate(code_objects(lib)):
+            if substr.encode() not in co:
+                continue
+            path = os.path.join(td, f"co{i}.o")
+            open(path, "wb").write(co)
+            txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", path], check=True,
+                                 capture_output=True, text=True).stdout
+            cur = None
+            for line in txt.split("\n"):
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if m:
+                    cur = m.group(1) if substr in m.group(1) else None
+                    if cur:
+                        out[cur] = []
+                elif cur and line.strip():
+                    out[cur].append(line.split("//")[0].strip())
+    return out
+
+
 if __name__ == "__main__":
     pat = sys.argv[1] if len(sys.argv) > 1 else ""
     ks = kernels()

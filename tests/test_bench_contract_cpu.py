@@ -73,3 +73,38 @@ def test_configs_match_baseline_json():
     assert len(base["configs"]) >= 5
     assert b.CONFIGS[3]["batch"] == 32 and b.CONFIGS[3]["seq"] == 144
     assert b.CONFIGS[4]["seq"] == 2048 and b.CONFIGS[5]["model"] == "real_13b" and b.CONFIGS[5]["fp8"]
+
+
+def test_bare_gpus_n_forms_the_torchrun_command_of_train_sh():
+    """`python bench.py --gpus 8 --steps K --warmup W` without a launcher re-executes itself as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py ...`
+    (the driver's own N > 1 form; /root/reference/train.sh:13), arguments forwarded verbatim."""
+    import sys
+    b = _bench()
+    cmd = b.self_launch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "3"], port=29400)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29400"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "3"]
+    p1, p2 = b._free_port(), b._free_port()
+    assert 1024 < p1 < 65536 and 1024 < p2 < 65536
+    # the prediction the first measured curve is read against travels in the line (comm.predicted_ms)
+    assert sorted(b.PREDICTED_CFG3) == [1, 2, 4, 8]
+    assert b.PREDICTED_CFG3[2]["speedup"][1] < 1.5 and "one xGMI link" in b.PREDICTED_CFG3[2]["note"]
+    assert all(len(v["step_ms"]) == 2 for v in b.PREDICTED_CFG3.values())
+
+
+def test_bare_gpus_n_without_a_gpu_fails_in_the_ranks_not_in_the_launcher(tmp_path):
+    """here (no GPU): the bare N = 2 call must really spawn the ranks -- each exits with the 'needs an MI355X' message
+    -- and hand their non-zero exit code back"""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_train_gpu.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=240, cwd=str(tmp_path))
+    assert r.returncode != 0
+    assert "needs an MI355X" in r.stderr and "torch.distributed" in r.stderr       # the message came from a spawned rank

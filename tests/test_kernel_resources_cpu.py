@@ -103,3 +103,32 @@ def test_attention_and_streaming_kernels_keep_their_occupancy(ks):
     for stem in ("gemm_skinny16_kernel", "gemm_skinny32p_kernel"):
         for k, v in _pick(ks, stem).items():
             assert v["vgpr_count"] <= 128, (k, v)          # weight streaming: two 8-wave workgroups per CU
+
+
+def test_no_compiler_code_touches_the_hand_placed_gemms_accumulator_registers():
+    """v9's 256 accumulators live in a0..a255 ACROSS asm statements (K loop -> compiler code that sets
+    up / requests the next tile -> the V9_ACC_READ asms) and are declared only as clobbers, so for the compiler the
+    AGPRs are free in between: a VGPR -> AGPR copy or spill placed there would silently corrupt the tile, and the
+    metadata counts above cannot see it.  Disassemble every *_v9_kernel: the ONLY instructions with an AGPR operand are
+    the MFMAs, `v_accvgpr_write_b32 aN, 0` (the loops' zeroing: 2 loop forms x 256) and `v_accvgpr_read_b32` with
+    every aN read equally often (2 epilogue forms x 256); no load, no copy from a VGPR."""
+    import collections
+    import re
+    dis = kr.disassemble("v9_kernel")
+    assert len(dis) == 8
+    areg = re.compile(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]")
+    for sym, lines in dis.items():
+        ops, reads = collections.Counter(), collections.Counter()
+        for ins in lines:
+            if not areg.search(ins):
+                continue
+            op = ins.split()[0]
+            ops[op] += 1
+            if op == "v_accvgpr_write_b32":
+                assert re.search(r"\ba\d+, 0$", ins), (sym, ins)          # zeroing only, never a value from a VGPR
+            elif op == "v_accvgpr_read_b32":
+                reads[int(areg.search(ins).group(1))] += 1
+            else:
+                assert op.startswith("v_mfma_f32_32x32x16_"), (sym, ins)   # no ds_read / buffer_load / v_mov into an AGPR
+        assert ops["v_accvgpr_write_b32"] == 512 and ops["v_accvgpr_read_b32"] == 512, (sym, dict(ops))
+        assert sorted(reads) == list(range(256)) and set(reads.values()) == {2}, sym
