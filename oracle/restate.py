@@ -118,9 +118,10 @@ def llama_layer(sd: SD, p: str, x, mask, position_ids, n_heads, eps, cos, sin):
 
 
 def llama_forward(sd: SD, p: str, inputs_embeds, attention_mask, cfg, labels=None,
-                  position_ids=None):
+                  position_ids=None, hidden_states=None):
     """modeling.py:397-522 (LlamaModel.forward) + 555-622 (LlamaForCausalLM.forward).
-    p = 'llm.'; returns (loss|None, logits)."""
+    p = 'llm.'; returns (loss|None, logits).  hidden_states: optional dict, filled with {depth: output of
+    decoder layer `depth` (1-based)} -- what `output_hidden_states` (:452-456,491-493) exposes."""
     B, S, D = inputs_embeds.shape
     n_layers, n_heads, eps = cfg["num_hidden_layers"], cfg["num_attention_heads"], cfg["rms_norm_eps"]
     if position_ids is None:
@@ -133,6 +134,8 @@ def llama_forward(sd: SD, p: str, inputs_embeds, attention_mask, cfg, labels=Non
     h = inputs_embeds
     for i in range(n_layers):
         h = llama_layer(sd, f"{p}model.layers.{i}.", h, mask, position_ids, n_heads, eps, cos, sin)
+        if hidden_states is not None:
+            hidden_states[i + 1] = h
     h = rms_norm(h, sd[p + "model.norm.weight"], eps)
     logits = F.linear(h, sd[p + "lm_head.weight"])
     loss = None
@@ -354,10 +357,10 @@ def prepare_inputs(sd: SD, inputs: dict, cfg: dict, hoist: bool = True):
     return text, am, lab, aux
 
 
-def mm_forward(sd: SD, inputs: dict, cfg: dict, hoist: bool = True):
+def mm_forward(sd: SD, inputs: dict, cfg: dict, hoist: bool = True, hidden_states=None):
     """modeling.py:941-963 (MM_LLMs.forward, training branch). Returns dict(loss, logits, ...)."""
     emb, am, lab, aux = prepare_inputs(sd, inputs, cfg, hoist)
-    loss, logits = llama_forward(sd, "llm.", emb, am, cfg["llama"], labels=lab)
+    loss, logits = llama_forward(sd, "llm.", emb, am, cfg["llama"], labels=lab, hidden_states=hidden_states)
     aux.update(inputs_embeds=emb, attention_mask=am, labels=lab, loss=loss, logits=logits)
     return aux
 
