@@ -337,6 +337,12 @@ int mk_adamw(void* param, float* master, float* m, float* v, const void* grad, i
              float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
              float grad_scale, int32_t dtype, void* stream);
 
+/* Caps mk_adamw's grid (blocks of 256 threads; 0 = default).  A small grid turns the grid-stride update into a
+ * persistent kernel that holds only a few CUs: the per-bucket updates of one rank then run BESIDE the backward's
+ * GEMMs (planned for fewer CUs through mk_gemm_set_cus) instead of as a serial tail -- the single-GPU counterpart of
+ * overlap_comm (configs/deepspeed_config.json:32).  Process-global like mk_gemm_set_cus; returns the previous cap. */
+int mk_adamw_set_max_blocks(int32_t n_blocks);
+
 /* A whole training step replayed from a hipGraph (macaw_llm_amd.train.GraphedStep) cannot change
  * kernel ARGUMENTS between steps; the two per-step scalars of the path live in device memory:
  *  - mk_adamw_multi_dev: mk_adamw_multi with hyper_dev = {lr, 1 - beta1^step, 1 - beta2^step,

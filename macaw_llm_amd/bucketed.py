@@ -270,6 +270,7 @@ class BucketedStep:
         # their rounds for (device CUs - comm_cus) -- scripts/probe/cu_hold.cpp: with 16 CUs held a 288-tile dx
         # GEMM runs at 1039 TFLOP/s planned for 256 CUs, 1196 planned for 240 (1270 alone)
         self.comm_cus = int(comm_cus) if (self.collective and overlap) else 0
+        self.local_cus = 0             # one rank, local_overlap: CUs the per-bucket AdamW launches may hold (below)
         self._cus_reserved = False
         self.last_step_skipped = False
         self._micro = 0
@@ -286,10 +287,25 @@ class BucketedStep:
         # 288-tile GEMM leaves are too short for it.  (With N ranks the same launches update 1/N of a bucket each and
         # the question does not arise.)  Same kernels, same arithmetic, same optimizer-state keys either way
         # (bit-identical weights: tests/test_train_gpu.py).
+        #
+        # Round 6: the CONFINED form, measured WORSE (profiles/r06_local_overlap_confined.txt) and therefore off
+        # (MACAW_LOCAL_CUS = 0).  With `local_cus` = c > 0 the launches behind the backward are capped at 8 c blocks
+        # (mk_adamw_set_max_blocks: the grid-stride kernel becomes a persistent update) and the GEMMs plan their rounds
+        # for 256 - c CUs (mk_gemm_set_cus, as for RCCL channels).  Step 222 ms serial / 224 unconfined / 241 (c = 8) /
+        # 287 (16) / 278 (24) / 260 (32) / 259 (48): the dispatcher does not PACK the blocks -- one resident 4-wave block
+        # is enough to keep a 256 x 256 GEMM workgroup (all 512 VGPRs per SIMD, 160 KiB LDS) off a CU, so 8 c blocks
+        # poison up to 8 c CUs -- and a CU streams ~22 GB/s (5.65 TB/s / 256), so an update confined to c CUs would need
+        # c ~ 75 to finish inside the backward.  AdamW on one rank costs 35 ms x 256 CUs wherever it is put.
+        #
         import os as _os
         if local_overlap is None:
             local_overlap = bool(_os.environ.get("MACAW_LOCAL_OVERLAP"))
         self.local_overlap = bool(local_overlap and overlap and not self.collective and dev.type == "cuda")
+        if self.local_overlap:
+            self.local_cus = max(0, int(_os.environ.get("MACAW_LOCAL_CUS", "0")))
+            self.comm_cus = self.local_cus
+            self.local_blocks = max(1, int(_os.environ.get("MACAW_LOCAL_BLOCKS", str(8 * self.local_cus)))) if self.local_cus else 0
+        self._in_finish = False
         if dev.type == "cuda" and overlap and self.collective:
             self.side = torch.cuda.Stream(device=dev)
         elif self.local_overlap:
@@ -507,13 +523,26 @@ class BucketedStep:
         _L.load().mk_gemm_set_cus(max(8, total - self.comm_cus) if on else 0)
         self._cus_reserved = on
 
+    def _adamw_cap(self, n_blocks: int) -> int:
+        """grid cap of the per-shard AdamW launches (process-global, read by the launcher on the host); returns the
+        previous cap"""
+        from . import lib as _L
+        return int(_L.load().mk_adamw_set_max_blocks(int(n_blocks)))
+
     def _launch(self, b: _Bucket):
         b.launched = True
         if not self.collective:
             if self.local_overlap and self._local_live and not self._needs_global():
+                confined = self.local_cus > 0 and not self._in_finish
+                if confined:
+                    self._reserve_cus(True)                             # the GEMMs that follow plan for 256 - c CUs
+                cap = self._adamw_cap(self.local_blocks if confined else 0)
                 self.side.wait_stream(torch.cuda.current_stream())      # the bucket's gradients are complete
-                with torch.cuda.stream(self.side):
-                    self._finish_bucket(b, self._acc_scale())
+                try:
+                    with torch.cuda.stream(self.side):
+                        self._finish_bucket(b, self._acc_scale())
+                finally:
+                    self._adamw_cap(cap)
                 b.updated = True
             return
         self._reserve_cus(True)
@@ -622,11 +651,15 @@ class BucketedStep:
             self._comm["ev0"].record()          # behind the last kernel of the backward on the compute stream
         if self._order is None:
             self._freeze_order()
-        while self._cursor < len(self._order):
-            b = self.buckets[self._order[self._cursor]]
-            self._zero_missing(b)
-            self._launch(b)
-            self._cursor += 1
+        self._in_finish = True                  # (local_overlap: the backward is over, these updates get the whole chip)
+        try:
+            while self._cursor < len(self._order):
+                b = self.buckets[self._order[self._cursor]]
+                self._zero_missing(b)
+                self._launch(b)
+                self._cursor += 1
+        finally:
+            self._in_finish = False
         queued = self.collective and not self._needs_global() and self.side is not None
         self.last_step_skipped = False
         if not queued:
@@ -817,7 +850,8 @@ class BucketedStep:
         nb = len(self.buckets)
         mb = sum(b.n * b.w.element_size() for b in self.buckets) / 2 ** 20
         if not self.collective:
-            mode = ("local (per-bucket AdamW launches behind the backward on a high-priority side stream)"
+            mode = ("local (per-bucket AdamW launches behind the backward on a high-priority side stream"
+                    + (f", confined to {self.local_blocks} blocks, GEMMs leave {self.local_cus} CUs" if self.local_cus else "") + ")"
                     if self.local_overlap and not self._needs_global() else "local (one fused AdamW launch)")
         elif self.zero1:
             mode = "ZeRO-1 reduce-scatter / shard AdamW / all-gather"

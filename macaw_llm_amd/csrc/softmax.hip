@@ -630,6 +630,17 @@ extern "C" int mk_cross_entropy_bwd(const void* logits, void* dlogits, const int
   return mk_check_launch();
 }
 
+// Upper bound on mk_adamw's grid (0 = the default 2048 blocks of 256 threads).  The kernel is a grid-stride stream,
+// so a small grid makes it a PERSISTENT update that holds only the CUs its blocks fit on (62 VGPRs: 8 blocks of four
+// waves per CU) -- how BucketedStep(local_overlap) runs the per-bucket updates of ONE rank beside the backward's GEMMs
+// on the CUs the GEMMs were told to leave (mk_gemm_set_cus), instead of taking every CU a finishing tile frees.
+static int g_adamw_max_blocks = 0;
+extern "C" int mk_adamw_set_max_blocks(int32_t n) {
+  const int prev = g_adamw_max_blocks;
+  g_adamw_max_blocks = n > 0 ? n : 0;
+  return prev;
+}
+
 extern "C" int mk_adamw(void* param, float* master, float* m, float* v, const void* grad,
                         int64_t n, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int32_t step, float grad_scale, int32_t dtype,
@@ -644,6 +655,7 @@ extern "C" int mk_adamw(void* param, float* master, float* m, float* v, const vo
   if (al & 15) return MK_ERR_UNSUPPORTED;
   long nb = (n / 8 + 255) / 256;
   if (nb > 2048) nb = 2048;
+  if (g_adamw_max_blocks > 0 && nb > g_adamw_max_blocks) nb = g_adamw_max_blocks;
   if (nb < 1) nb = 1;
   dim3 grid((unsigned)nb), block(256);
   if (dtype == MK_BF16)
