@@ -134,6 +134,7 @@ int main(int argc, char** argv) {
   const int reps = argc > 3 ? atoi(argv[3]) : 8;
   std::vector<unsigned> h(4096 * 4);
   unsigned s = 12345u;
+  const bool zeros = getenv("MP_ZEROS") != nullptr;      // all-zero operands: no data toggling -> how much of the limit is POWER
   for (auto& v : h) {
     // two random bf16 in [-2, 2): sign + exponent 0x3f / 0x3e / 0x40 + random mantissa
     unsigned a[2];
@@ -142,14 +143,14 @@ int main(int argc, char** argv) {
       const unsigned e = 0x3e + ((s >> 9) % 3);
       a[k] = ((s >> 31) << 15) | (e << 7) | ((s >> 12) & 0x7f);
     }
-    v = a[0] | (a[1] << 16);
+    v = zeros ? 0u : (a[0] | (a[1] << 16));
   }
   u32x4* src;
   float* out;
   CK(hipMalloc(&src, 65536));
   CK(hipMalloc(&out, (size_t)grid * 256 * 4));
   CK(hipMemcpy(src, h.data(), 65536, hipMemcpyHostToDevice));
-  printf("mode,what,tflops\n");
+  printf("operands: %s\nmode,what,tflops\n", zeros ? "all zeros" : "random bf16 in [-4, 4)");
   for (int round = 0; round < 2; ++round) {
     printf("0,32x32x16 registers only,%.1f\n", run<0>(src, out, grid, iters, reps));
     printf("1,16x16x32 registers only,%.1f\n", run<1>(src, out, grid, iters, reps));

@@ -31,28 +31,53 @@ def fq_rows(t):
     return (q.view(torch.float8_e4m3fn).float() * s[:, None]).reshape(shp).to(t.dtype)
 
 
+def fq_blocks32(t):
+    """fake quantisation with the block scales v_mfma_scale_f32_32x32x64_f8f6f4 takes natively (OCP MX): one E8M0
+    (power-of-two) scale per 32 consecutive elements of the reduction (last) dimension, elements e4m3.  The scale is
+    the smallest power of two that keeps the block's largest magnitude <= 448 (2^ceil(log2(amax / 448)): no clipping --
+    kinder than the OCP MX rule floor(log2 amax) - 8, which saturates magnitudes in (448, 512) x scale)."""
+    shp = t.shape
+    K = shp[-1]
+    pad = (-K) % 32
+    x = t.reshape(-1, K).float()
+    if pad:
+        x = torch.nn.functional.pad(x, (0, pad))
+    xb = x.view(x.shape[0], -1, 32)
+    amax = xb.abs().amax(dim=-1, keepdim=True)
+    e = torch.ceil(torch.log2(amax.clamp_min(2.0 ** -120) / 448.0))
+    sc = torch.exp2(e)
+    q = (xb / sc).clamp(-448, 448).to(torch.float8_e4m3fn).float() * sc
+    q = torch.where(amax > 0, q, torch.zeros_like(q)).view(x.shape[0], -1)
+    return q[:, :K].reshape(shp).to(t.dtype)
+
+
+FQ = fq_rows          # the operand quantiser of the yardstick; fake_quant_oracle(scheme="blocks32") swaps fq_blocks32 in
+
+
 class _FakeQuantLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
         ctx.has_b = b is not None
-        y = fq_rows(x) @ fq_rows(W).t()
+        y = FQ(x) @ FQ(W).t()
         return y + b if b is not None else y
 
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
-        dx = fq_rows(dy) @ fq_rows(W.t()).t()                 # W^T with one scale per input channel
+        dx = FQ(dy) @ FQ(W.t()).t()                           # W^T with one scale per input channel (rows: along the reduction)
         dW = dy.reshape(-1, dy.shape[-1]).t() @ x.reshape(-1, x.shape[-1])     # grad-weight stays unquantised
         db = dy.reshape(-1, dy.shape[-1]).sum(0) if ctx.has_b else None
         return dx, dW, db
 
 
 @contextlib.contextmanager
-def fake_quant_oracle(sites=("qkv", "align")):
-    old = restate.FP8_LINEAR, restate.FP8_SITES
+def fake_quant_oracle(sites=("qkv", "align"), scheme="rows"):
+    global FQ
+    old = restate.FP8_LINEAR, restate.FP8_SITES, FQ
     restate.FP8_LINEAR, restate.FP8_SITES = (lambda x, W, b=None: _FakeQuantLinear.apply(x, W, b)), tuple(sites)
+    FQ = {"rows": fq_rows, "blocks32": fq_blocks32}[scheme]
     try:
         yield
     finally:
-        restate.FP8_LINEAR, restate.FP8_SITES = old
+        restate.FP8_LINEAR, restate.FP8_SITES, FQ = old
