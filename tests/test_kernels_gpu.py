@@ -1037,6 +1037,37 @@ def test_adamw_multi_tensor_is_bit_identical_to_per_tensor(dev):
             assert torch.equal(oa.state[p][1], ob.state[q][1]) and torch.equal(oa.state[p][2], ob.state[q][2])
 
 
+def test_adamw_grid_cap_changes_nothing_but_the_grid(dev):
+    """mk_adamw_set_max_blocks (the persistent / confined form of the per-shard update, profiles/r06_local_overlap_confined.txt):
+    every element is updated exactly once whatever the cap -- bit-identical parameters and moments for caps 1, 7, 64 and
+    the default grid on a ragged length; the call returns the previous cap and 0 restores the default."""
+    from macaw_llm_amd import lib as _L
+    g = torch.Generator().manual_seed(91)
+    n = 3 * 1024 * 1024 + 13 * 8
+    w0 = _rand((n,), torch.bfloat16, g)
+    grad = _rand((n,), torch.bfloat16, g).to(dev)
+    lib = _L.load()
+
+    def run(cap):
+        prev = lib.mk_adamw_set_max_blocks(cap)
+        assert prev == 0
+        try:
+            param = w0.clone().to(dev)
+            master, m, v = param.float(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+            for step in (1, 2):
+                ops.adamw_(param, master, m, v, grad, 1e-2, 0.9, 0.999, 1e-8, 0.01, step)
+            torch.cuda.synchronize()
+        finally:
+            assert lib.mk_adamw_set_max_blocks(0) == cap
+        return param, master, m, v
+
+    ref = run(0)
+    for cap in (1, 7, 64):
+        got = run(cap)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), cap
+
+
 def test_adamw_unaligned_slice_and_param_groups(dev):
     """a parameter that is an odd-offset slice of a fused buffer (not 16-byte aligned)
     used to hit MK_ERR_UNSUPPORTED in the 'fallback'; it now goes through an aligned staging copy
