@@ -81,7 +81,7 @@ def pmc_gemm_traffic(config: int, mk_gemm_launches: int = 0):
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     suffix = "" if config == 3 else f"_cfg{config}"
     path = None
-    for rnd in ("r05", "r04h", "r04f", "r03f", "r03", "r02", "r01"):      # newest first (rNNf / rNNh = final binary of round NN)
+    for rnd in ("r06", "r05", "r04h", "r04f", "r03f", "r03", "r02", "r01"):      # newest first (rNNf / rNNh = final binary of round NN)
         cand = os.path.join(here, f"{rnd}_step_traffic_pmc{suffix}.csv")
         if os.path.exists(cand):
             path = cand

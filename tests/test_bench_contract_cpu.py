@@ -24,7 +24,8 @@ def _line(name):
         return json.loads(f.read().strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("name", ["r05_bench_cfg3.json", "r05_bench_cfg2.json", "r05_bench_cfg4.json", "r05_bench_cfg5.json",
+@pytest.mark.parametrize("name", ["r06_bench_cfg3.json", "r06_bench_cfg2.json", "r06_bench_cfg4.json", "r06_bench_cfg5.json",
+                                  "r05_bench_cfg3.json", "r05_bench_cfg2.json", "r05_bench_cfg4.json", "r05_bench_cfg5.json",
                                   "r04h_bench_cfg3.json", "r04h_bench_cfg2.json", "r04h_bench_cfg4.json",
                                   "r04h_bench_cfg5.json", "r03f_bench_cfg3.json"])
 def test_committed_bench_lines_carry_the_contract(name):
@@ -56,9 +57,9 @@ def test_traffic_is_looked_up_per_configuration_and_null_without_a_profile():
     t2, src2 = b.pmc_gemm_traffic(2)
     t4, src4 = b.pmc_gemm_traffic(4)
     t5, src5 = b.pmc_gemm_traffic(5)
-    # (newest committed profile of each configuration: round 5 for cfg 2 / 3 / 4; the 13B PMC passes were not repeated)
-    assert src3 == "r05_step_traffic_pmc.csv" and src2 == "r05_step_traffic_pmc_cfg2.csv"
-    assert src4 == "r05_step_traffic_pmc_cfg4.csv" and "cfg5" in src5
+    # (newest committed profile of each configuration: round 6 for all four)
+    assert src3 == "r06_step_traffic_pmc.csv" and src2 == "r06_step_traffic_pmc_cfg2.csv"
+    assert src4 == "r06_step_traffic_pmc_cfg4.csv" and src5 == "r06_step_traffic_pmc_cfg5.csv"
     assert len({t3, t2, t4, t5}) == 4 and all(3e8 < t < 2e9 for t in (t3, t2, t4, t5))     # bytes per launch
     assert b.pmc_gemm_traffic(1) == (None, None)          # no PMC profile of cfg 1 (the CPU plumbing case) exists
     # (a committed line carries the figure of the newest profile that existed when it was printed)
