@@ -2,9 +2,10 @@
 (/root/reference/modeling.py through oracle/ref_loader.py) with CLIP-ViT-L/14 + alignment attention +
 the 32-layer LLaMA-7B, image-only, batch 1, fp32, on this container's CPU (8 B parameters = 32 GB of the
 62 GB), and a second fixture with the real Whisper-base + 6-frame CLIP video path (audio + video, LLaMA
-truncated to 2 layers: the stack is pinned by the first fixture).
+truncated to 2 layers: the stack is pinned by the first fixture), and a third with the BACKWARD (image + audio, B = 2,
+2-layer LLaMA: weights + gradients fit): the reference's own gradients at V = 32,007 / D = 4096 as row subsets + norms.
 
-    python -m oracle.make_golden_cfg1            # writes tests/golden/cfg1_full.pt, real_av_trunc.pt
+    python -m oracle.make_golden_cfg1            # writes tests/golden/cfg1_full.pt, real_av_trunc.pt, real_grad_trunc.pt
 
 Weights and inputs are NOT stored: every hot-path parameter is a pure integer-hash function of its name
 (oracle/hashweights.py), identical on CPU and GPU, so tests regenerate them.  Stored: the reference's
@@ -46,6 +47,68 @@ def build_hashed_reference(cfg):
           f"({sum(torch.Size(s).numel() for s in shapes.values()) / 1e9:.2f} B values) hashed in {time.time() - t1:.0f} s",
           file=sys.stderr)
     return model.eval(), shapes
+
+
+GRAD_ROWS = {   # reference gradients stored as row subsets (the full tensors are 64-525 MB each) + the L2 norm of every gradient
+    "llm.model.embed_tokens.weight": [0, 1, 2, 3, 777, 12345, 31999, 32000, 32001, 32002, 32003, 32004, 32005, 32006],
+    "llm.lm_head.weight": [0, 1, 5, 4242, 32006],
+    "llm.model.norm.weight": None,                                     # None = the whole tensor
+    "llm.model.layers.1.mlp.down_proj.weight": [0, 1, 2047, 4095],
+    "llm.model.layers.1.self_attn.q_proj.weight": [0, 129, 4095],
+    "llm.model.layers.0.mlp.gate_proj.weight": [0, 5000, 11007],
+    "llm.model.layers.0.self_attn.v_proj.weight": [0, 2048, 4095],
+    "llm.model.layers.0.input_layernorm.weight": None,
+    "image_align_attention.in_proj_weight": [0, 1, 4096, 4097, 8192, 12287],   # rows of the q / k / v thirds
+    "image_align_attention.in_proj_bias": None,
+    "image_align_attention.bias_k": None,
+    "image_align_attention.out_proj.weight": [0, 4095],
+    "audio_align_attention.in_proj_weight": [5, 4101, 8197],
+    "audio_align_attention.bias_v": None,
+    "audio_align_attention.out_proj.bias": None,
+    "project_image.weight": [0, 767],
+    "project_image.bias": None,
+    "project_audio.weight": [0, 511],
+    "transform_image_to_hidden.weight": [0, 4095],
+    "transform_audio_to_hidden.bias": None,
+}
+
+
+def run_with_grads(name, cfg, batch, text_len, modalities):
+    """forward + BACKWARD of the reference at real dimensions (LLaMA truncated so that weights + gradients fit): the
+    training recipe's freeze (run_clm_llms.py:390-393), eval mode (dropout off), loss.backward()"""
+    model, shapes = build_hashed_reference(cfg)
+    for n, p in model.named_parameters():
+        p.requires_grad_("encoder" not in n)
+    inp = hw.make_inputs(cfg, batch, text_len, modalities, tag=name, n_prompt=8)
+    t0 = time.time()
+    out = model(inputs=inp)
+    out.loss.backward()
+    with torch.no_grad():
+        emb, am, lab = model.prepare_inputs_for_generation(inp)
+    S = emb.shape[1]
+    pos = _positions(S)
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    fx = dict(
+        name=name, config_name="real_7b", llama_layers=cfg["llama"]["num_hidden_layers"], text_len=text_len, batch=batch,
+        modalities=tuple(modalities), shapes=shapes, positions=pos, n_prompt=8,
+        inputs_embeds=emb.detach().clone(), attention_mask=am, labels=lab,
+        logits_at=out.logits[:, pos].detach().clone(), argmax_ids=out.logits.argmax(-1),
+        logit_absmax=out.logits.abs().max().item(), loss=out.loss.detach().clone(),
+        grad_norms={n: g.norm().item() for n, g in grads.items()},
+        grad_absmax={n: g.abs().max().item() for n, g in grads.items()},
+        grad_rows={n: (grads[n].detach().clone() if rows is None else grads[n][rows].detach().clone())
+                   for n, rows in GRAD_ROWS.items()},
+        grad_row_index=GRAD_ROWS,
+        no_grad_params=sorted(n for n, p in model.named_parameters() if p.requires_grad and p.grad is None),
+        source="reference MM_LLMs.forward + loss.backward() (modeling.py:941-1048, 555-622), CPU fp32, "
+               f"torch {torch.__version__}",
+    )
+    path = os.path.join(GOLDEN_DIR, name + ".pt")
+    torch.save(fx, path)
+    print(f"{name}: S={S} loss={out.loss.item():.6f} {len(grads)} gradients, forward + backward {time.time() - t0:.0f} s, "
+          f"{os.path.getsize(path) / 1e6:.2f} MB", file=sys.stderr)
+    del model
+    return fx
 
 
 def run(name, cfg, text_len, modalities, depths):
@@ -111,7 +174,11 @@ def run(name, cfg, text_len, modalities, depths):
 
 def main():
     torch.set_num_threads(os.cpu_count() or 8)
-    which = sys.argv[1:] or ["real_av_trunc", "cfg1_full"]
+    which = sys.argv[1:] or ["real_av_trunc", "real_grad_trunc", "cfg1_full"]
+    if "real_grad_trunc" in which:
+        cfg = configs.get("real_7b")
+        cfg["llama"]["num_hidden_layers"] = 2
+        run_with_grads("real_grad_trunc", cfg, 2, 32, ("images", "audios"))
     if "real_av_trunc" in which:
         cfg = configs.get("real_7b")
         cfg["llama"]["num_hidden_layers"] = 2

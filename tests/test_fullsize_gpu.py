@@ -863,3 +863,44 @@ def test_bf16_engine_against_the_reference_itself_at_full_size(dev, name):
     assert hip[0] <= 0.10 and hip[1] <= 0.08, hip
     assert abs(out.loss.item() - fx["loss"].item()) <= 2e-2 * max(1.0, abs(fx["loss"].item()))
     assert emb_err <= 5e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gradients_against_the_reference_itself_at_real_dimensions(dev, dtype):
+    """tests/golden/real_grad_trunc.pt = forward + loss.backward() of the REFERENCE's own MM_LLMs at real dimensions (CLIP-L/14
+    + Whisper-base + both alignment attentions over the 32,007-row table + 2 LLaMA-7B layers + lm_head, image + audio, B = 2,
+    encoders frozen as run_clm_llms.py:390-393).  The HIP engines on the same hash weights: INT outputs bit-exact, the same
+    set of parameters receives a gradient; fp32: logits within 1e-3, stored gradient rows within 2e-4 of the gradient's
+    largest magnitude and every L2 norm within 1e-3; bf16: rows within 5e-2 relative L2, norms within 5e-2."""
+    from oracle import hashweights as hw
+    fx = _load_fullsize("real_grad_trunc")
+    model, cfg, _ = _hashed_model(dev, fx, dtype)
+    inp = hw.make_inputs(cfg, fx["batch"], fx["text_len"], fx["modalities"], tag=fx["name"], n_prompt=fx["n_prompt"], device=dev)
+    model.zero_grad(set_to_none=True)
+    out = model(inputs=inp)
+    out.loss.backward()
+    with torch.no_grad():
+        emb, am, lab = model.prepare_inputs_for_generation(inp)
+    pos = fx["positions"]
+    assert torch.equal(am.cpu(), fx["attention_mask"]) and torch.equal(lab.cpu(), fx["labels"])
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None and n in fx["shapes"]}
+    assert set(grads) == set(fx["grad_norms"]), set(grads) ^ set(fx["grad_norms"])
+    e_log = (out.logits.float().cpu()[:, pos] - fx["logits_at"]).abs().max().item()
+    rows, norms = {}, {}
+    for name, want in fx["grad_rows"].items():
+        idx = fx["grad_row_index"][name]
+        got = grads[name].detach().float().cpu()
+        got = got if idx is None else got[idx]
+        rows[name] = ((got - want).abs().max().item() / fx["grad_absmax"][name], ((got - want).norm() / want.norm()).item())
+    for name, n in fx["grad_norms"].items():
+        norms[name] = abs(grads[name].detach().float().norm().item() - n) / n
+    wr, wl, wn = max(v[0] for v in rows.values()), max(v[1] for v in rows.values()), max(norms.values())
+    print(f"real_grad_trunc {dtype}: vs the REFERENCE's backward: |d logits| {e_log:.3e}, |d loss| "
+          f"{abs(out.loss.item() - fx['loss'].item()):.3e}; gradient rows worst max-err / max|g| {wr:.3e}, worst rel L2 {wl:.3e}; "
+          f"worst norm error {wn:.3e} over {len(norms)} gradients")
+    if dtype == torch.float32:
+        assert e_log <= 1e-3 and abs(out.loss.item() - fx["loss"].item()) <= 1e-4
+        assert wr <= 2e-4 and wn <= 1e-3, (rows, norms)
+    else:
+        assert abs(out.loss.item() - fx["loss"].item()) <= 2e-2 * abs(fx["loss"].item())
+        assert wl <= 5e-2 and wn <= 5e-2, (rows, norms)

@@ -139,6 +139,64 @@ def test_restatement_matches_reference_with_real_whisper_and_video_encoders():
     _check_fullsize(fx, r, hidden, 5e-5)
 
 
+class _LazyHashDict(dict):
+    """state dict that materialises hash weights on first access and KEEPS them (autograd leaves): every tensor outside
+    the frozen towers requires grad, as run_clm_llms.py:390-393 leaves it"""
+
+    def __init__(self, shapes, device=None):
+        super().__init__()
+        self.shapes, self.device = shapes, device
+
+    def __missing__(self, key):
+        from oracle import hashweights as hw
+        t = hw.hash_tensor(key, self.shapes[key], self.device).requires_grad_("encoder" not in key)
+        self[key] = t
+        return t
+
+
+def check_reference_gradients(fx, grads, tol_rows, tol_norm):
+    """`grads`: {name: full gradient tensor} of a run on fx's weights / inputs; compared with the REFERENCE's stored rows
+    (max error relative to the reference gradient's largest magnitude) and with the L2 norms of ALL its gradients"""
+    worst = {}
+    for name, want in fx["grad_rows"].items():
+        rows = fx["grad_row_index"][name]
+        got = grads[name].detach().float().cpu()
+        got = got if rows is None else got[rows]
+        worst[name] = (got - want).abs().max().item() / fx["grad_absmax"][name]
+        assert worst[name] <= tol_rows, (name, worst[name])
+    for name, n in fx["grad_norms"].items():
+        assert name in grads, name
+        assert abs(grads[name].detach().float().norm().item() - n) <= tol_norm * n, (name, n)
+    return worst
+
+
+def test_restated_backward_matches_the_references_gradients_at_real_dimensions():
+    """tests/golden/real_grad_trunc.pt: forward + loss.backward() of the reference's own MM_LLMs at real dimensions
+    (CLIP-L/14 + Whisper-base + both alignment attentions over the 32,007-row table + 2 LLaMA-7B layers + lm_head at
+    V = 32,007, image + audio, B = 2, encoders frozen).  Autograd through the restatement on the same hash weights must
+    reproduce its 41 gradients: stored rows within 2e-5 of the largest magnitude, every L2 norm within 1e-4; the set
+    of parameters that receive a gradient is the reference's."""
+    import os
+    from golden_util import GOLDEN_DIR
+    from oracle import hashweights as hw
+    fx = torch.load(os.path.join(GOLDEN_DIR, "real_grad_trunc.pt"), weights_only=False)
+    cfg = configs.get(fx["config_name"])
+    cfg["llama"]["num_hidden_layers"] = fx["llama_layers"]
+    inp = hw.make_inputs(cfg, fx["batch"], fx["text_len"], fx["modalities"], tag=fx["name"], n_prompt=fx["n_prompt"])
+    sd = _LazyHashDict(fx["shapes"])
+    r = restate.mm_forward(sd, inp, cfg)
+    r["loss"].backward()
+    pos = fx["positions"]
+    assert torch.equal(r["attention_mask"], fx["attention_mask"]) and torch.equal(r["labels"], fx["labels"])
+    assert (r["logits"][:, pos].detach() - fx["logits_at"]).abs().max().item() <= 5e-5
+    assert abs(r["loss"].item() - fx["loss"].item()) <= 1e-5
+    grads = {k: v.grad for k, v in sd.items() if v.grad is not None}
+    assert set(grads) == set(fx["grad_norms"])                      # who gets a gradient: as in the reference
+    worst = check_reference_gradients(fx, grads, 2e-5, 1e-4)
+    print("real_grad_trunc: restated gradients vs the reference (max err / max |g|):",
+          {k.split(".", 1)[-1][-40:]: f"{v:.1e}" for k, v in worst.items()})
+
+
 def test_hash_weights_are_a_pure_integer_function_of_name_and_index():
     """the fixtures above rest on every box regenerating the same tensors: known answers of the recipe (any device /
     torch version must reproduce them -- tests/test_fullsize_gpu.py repeats this on the GPU), bf16-exactness,
