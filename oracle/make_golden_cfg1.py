@@ -94,7 +94,8 @@ def run_with_grads(name, cfg, batch, text_len, modalities):
         inputs_embeds=emb.detach().clone(), attention_mask=am, labels=lab,
         logits_at=out.logits[:, pos].detach().clone(), argmax_ids=out.logits.argmax(-1),
         logit_absmax=out.logits.abs().max().item(), loss=out.loss.detach().clone(),
-        grad_norms={n: g.norm().item() for n, g in grads.items()},
+        # (float64: a float32 sum of 45 M squares on the CPU is itself off by ~0.5 %)
+        grad_norms={n: g.double().norm().item() for n, g in grads.items()},
         grad_absmax={n: g.abs().max().item() for n, g in grads.items()},
         grad_rows={n: (grads[n].detach().clone() if rows is None else grads[n][rows].detach().clone())
                    for n, rows in GRAD_ROWS.items()},

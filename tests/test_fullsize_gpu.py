@@ -893,8 +893,9 @@ def test_gradients_against_the_reference_itself_at_real_dimensions(dev, dtype):
         got = got if idx is None else got[idx]
         rows[name] = ((got - want).abs().max().item() / fx["grad_absmax"][name], ((got - want).norm() / want.norm()).item())
     for name, n in fx["grad_norms"].items():
-        norms[name] = abs(grads[name].detach().float().norm().item() - n) / n
+        norms[name] = abs(grads[name].detach().double().norm().item() - n) / n          # float64 on both sides
     wr, wl, wn = max(v[0] for v in rows.values()), max(v[1] for v in rows.values()), max(norms.values())
+    print("  norm errors > 1e-4:", {k: f"{v:.2e}" for k, v in sorted(norms.items(), key=lambda kv: -kv[1]) if v > 1e-4})
     print(f"real_grad_trunc {dtype}: vs the REFERENCE's backward: |d logits| {e_log:.3e}, |d loss| "
           f"{abs(out.loss.item() - fx['loss'].item()):.3e}; gradient rows worst max-err / max|g| {wr:.3e}, worst rel L2 {wl:.3e}; "
           f"worst norm error {wn:.3e} over {len(norms)} gradients")

@@ -166,7 +166,7 @@ def check_reference_gradients(fx, grads, tol_rows, tol_norm):
         assert worst[name] <= tol_rows, (name, worst[name])
     for name, n in fx["grad_norms"].items():
         assert name in grads, name
-        assert abs(grads[name].detach().float().norm().item() - n) <= tol_norm * n, (name, n)
+        assert abs(grads[name].detach().double().norm().item() - n) <= tol_norm * n, (name, n)     # float64 on both sides
     return worst
 
 
