@@ -871,7 +871,7 @@ def test_gradients_against_the_reference_itself_at_real_dimensions(dev, dtype):
     + Whisper-base + both alignment attentions over the 32,007-row table + 2 LLaMA-7B layers + lm_head, image + audio, B = 2,
     encoders frozen as run_clm_llms.py:390-393).  The HIP engines on the same hash weights: INT outputs bit-exact, the same
     set of parameters receives a gradient; fp32: logits within 1e-3, stored gradient rows within 2e-4 of the gradient's
-    largest magnitude and every L2 norm within 1e-3; bf16: rows within 5e-2 relative L2, norms within 5e-2."""
+    largest magnitude and every L2 norm within 1e-3; bf16: rows within 5e-2 of the largest magnitude, norms within 2e-2."""
     from oracle import hashweights as hw
     fx = _load_fullsize("real_grad_trunc")
     model, cfg, _ = _hashed_model(dev, fx, dtype)
@@ -904,4 +904,7 @@ def test_gradients_against_the_reference_itself_at_real_dimensions(dev, dtype):
         assert wr <= 2e-4 and wn <= 1e-3, (rows, norms)
     else:
         assert abs(out.loss.item() - fx["loss"].item()) <= 2e-2 * abs(fx["loss"].item())
-        assert wl <= 5e-2 and wn <= 5e-2, (rows, norms)
+        # (row subsets with tiny magnitudes -- table rows that only see the dense alignment gradient -- make a per-row
+        #  relative L2 meaningless in bf16: the bound is on the error relative to the gradient's largest magnitude, measured
+        #  2.0e-2, and on the norms, measured 3.6e-3)
+        assert wr <= 5e-2 and wn <= 2e-2, (rows, norms)
