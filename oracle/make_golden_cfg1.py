@@ -104,8 +104,20 @@ def run_with_grads(name, cfg, batch, text_len, modalities):
         source="reference MM_LLMs.forward + loss.backward() (modeling.py:941-1048, 555-622), CPU fp32, "
                f"torch {torch.__version__}",
     )
+    # greedy decode through the REFERENCE's own cached forward (modeling.py:183-195 KV cache, :624-659
+    # prepare_inputs_for_generation) from this multimodal prefix, at real width: ids + the top-1 / top-2 margin of every step
+    # (a consumer compares ids only where the margin exceeds its own logit error)
+    from .make_golden import reference_greedy
+    with torch.no_grad():
+        ids = reference_greedy(model.llm, emb.detach(), max_new_tokens=12, eos=2, pad=cfg["tags"]["pad"])
+        full = torch.cat([emb.detach(), torch.nn.functional.embedding(ids, model.llm.model.embed_tokens.weight)], 1)
+        z = model.llm(inputs_embeds=full).logits[:, S - 1:S - 1 + ids.shape[1]]
+        top2 = z.topk(2, dim=-1).values
+    fx["generate_ids"], fx["generate_margin"] = ids, (top2[..., 0] - top2[..., 1])
+    fx["generate_ids_source"] = "reference LlamaForCausalLM.forward + past_key_values, greedy loop of make_golden.reference_greedy"
     path = os.path.join(GOLDEN_DIR, name + ".pt")
     torch.save(fx, path)
+    print(f"  generate ids {ids.tolist()} margins min {fx['generate_margin'].min().item():.4f}", file=sys.stderr)
     print(f"{name}: S={S} loss={out.loss.item():.6f} {len(grads)} gradients, forward + backward {time.time() - t0:.0f} s, "
           f"{os.path.getsize(path) / 1e6:.2f} MB", file=sys.stderr)
     del model

@@ -197,6 +197,24 @@ def test_restated_backward_matches_the_references_gradients_at_real_dimensions()
           {k.split(".", 1)[-1][-40:]: f"{v:.1e}" for k, v in worst.items()})
 
 
+def test_restated_greedy_loop_matches_the_references_cached_decode_at_real_width():
+    """real_grad_trunc.pt also holds 12 greedy ids per sample produced by the REFERENCE's forward with its own KV cache
+    (oracle/make_golden.reference_greedy) from the multimodal prefix at D = 4096 / V = 32,007: the restated
+    full-recompute loop emits the same ids (smallest top-1 / top-2 margin on the path: 8.5e-3)."""
+    import os
+    from golden_util import GOLDEN_DIR
+    fx = torch.load(os.path.join(GOLDEN_DIR, "real_grad_trunc.pt"), weights_only=False)
+    cfg = configs.get(fx["config_name"])
+    cfg["llama"]["num_hidden_layers"] = fx["llama_layers"]
+    from oracle import hashweights as hw
+    sd = hw.HashState({k: v for k, v in fx["shapes"].items() if k.startswith("llm.")}, keep=[k for k in fx["shapes"] if k.startswith("llm.")])
+    with torch.no_grad():
+        ids = restate.greedy_generate(sd, fx["inputs_embeds"], cfg, max_new_tokens=12, eos=2, pad=cfg["tags"]["pad"])
+    assert fx["generate_ids_source"].startswith("reference LlamaForCausalLM.forward + past_key_values")
+    assert fx["generate_margin"].min().item() > 5e-3
+    assert torch.equal(ids, fx["generate_ids"])
+
+
 def test_hash_weights_are_a_pure_integer_function_of_name_and_index():
     """the fixtures above rest on every box regenerating the same tensors: known answers of the recipe (any device /
     torch version must reproduce them -- tests/test_fullsize_gpu.py repeats this on the GPU), bf16-exactness,
