@@ -24,6 +24,7 @@
 #include "../../include/macaw_hip.h"
 #include "gemm_common.h"
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <utility>
 #include <vector>
@@ -367,7 +368,12 @@ int pick_cfg(const mk_gemm_desc* d, int nbatch, bool v7_ok, int n_cus) {
     if (sp > nk2 / 2) sp = nk2 / 2;
     if (sp > 64) sp = 64;
     if (sp < 1) sp = 1;
-    t2 = nk / sp * a2 + 2.0 + (sp > 1 ? 4.0 + 0.65 * sp : 0.0);
+    // a2 is the K-tile time of a workgroup that SHARES its CU with another one; with sp == 1 and T2 barely above the CU
+    // count most workgroups have a CU to themselves and run 0.93 ... 1.04 us per K-tile instead of 1.67 (round 6, cold
+    // harness, profiles/r06_gemm_cfg2_enc.csv: 4112 x 1024 x 4096 61 us on v2 against 79 on v7 where this model said 109;
+    // 4112 x 1024 x 1024 18.7 against 27.4) -- CLIP's out-proj / fc2 at 16 images per GPU (BASELINE cfg 2)
+    const double alone = sp > 1 ? 1.0 : 0.57 + 0.43 * std::min(1.0, std::max(0.0, (double)T2 / n_cus - 1.0));
+    t2 = nk / sp * a2 * alone + 2.0 + (sp > 1 ? 4.0 + 0.65 * sp : 0.0);
   } else {
     t2 = (double)T2 / slots2 * tile2;
     if (const long R2 = T2 % slots2) {   // K-split tail: pieces + the last arriver reading `sp` slabs
