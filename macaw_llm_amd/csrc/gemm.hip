@@ -373,7 +373,10 @@ int pick_cfg(const mk_gemm_desc* d, int nbatch, bool v7_ok, int n_cus) {
     // harness, profiles/r06_gemm_cfg2_enc.csv: 4112 x 1024 x 4096 61 us on v2 against 79 on v7 where this model said 109;
     // 4112 x 1024 x 1024 18.7 against 27.4) -- CLIP's out-proj / fc2 at 16 images per GPU (BASELINE cfg 2)
     const double alone = sp > 1 ? 1.0 : 0.57 + 0.43 * std::min(1.0, std::max(0.0, (double)T2 / n_cus - 1.0));
-    t2 = nk / sp * a2 * alone + 2.0 + (sp > 1 ? 4.0 + 0.65 * sp : 0.0);
+    // fix-up: ONE workgroup per tile reads `sp` fp32 slabs of 64 KiB at a single CU's rate (34 GB/s,
+    // profiles/r06_local_overlap_confined.txt): 1.6 us per slab, not 0.65 -- 192 x 768 x 4096 and 192 x 512 x 4096 (grad-input
+    // of the modality projections) took 62 / 59 us here against 26 on the 256 x 256 kernel (profiles/r06_gemm_policy_sweep.csv)
+    t2 = nk / sp * a2 * alone + 2.0 + (sp > 1 ? 4.0 + 1.6 * sp : 0.0);
   } else {
     t2 = (double)T2 / slots2 * tile2;
     if (const long R2 = T2 % slots2) {   // K-split tail: pieces + the last arriver reading `sp` slabs
