@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE ONLY. Device-independent, version-independent weights and inputs for the
-FULL-SIZE reference fixtures (oracle/make_golden_cfg1.py, tests/golden/cfg1_full.pt, real_av_trunc.pt).
+FULL-SIZE reference fixtures (oracle/make_golden_cfg1.py -> tests/golden/cfg1_full.pt, real_av_trunc.pt, real_grad_trunc.pt).
 
 The reference at BASELINE cfg 1 (CLIP-L/14 + alignment + 32-layer LLaMA-7B, fp32) has 8 B parameters:
 32 GB cannot be committed, and `torch.randn` streams differ between CPU and GPU generators.  Every
