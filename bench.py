@@ -301,7 +301,11 @@ def main():
         # bare `python bench.py --gpus N` (how the driver invokes N = 1): start the N ranks ourselves, exactly as
         # train.sh:13 does (torchrun --nnodes 1 --nproc_per_node N); rank 0's JSON line and the ranks' stderr pass
         # straight through, the exit code is the launcher's
-        raise SystemExit(subprocess.call(self_launch_command(args.gpus, sys.argv[1:])))
+        import signal
+        proc = subprocess.Popen(self_launch_command(args.gpus, sys.argv[1:]))
+        for sig in (signal.SIGTERM, signal.SIGINT):       # a driver that stops us stops the ranks (torchrun tears them down)
+            signal.signal(sig, lambda s, _f: proc.send_signal(s))
+        raise SystemExit(proc.wait())
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
