@@ -479,6 +479,38 @@ __global__ __launch_bounds__(256) void fp8_rowquant_kernel(const bf16* x, long l
   }
 }
 
+// Round 6: the row stays in REGISTERS between the amax pass and the quantisation (CH chunks of 8 per thread: rows of up
+// to 2048 * CH elements) -- one load per element instead of two dependent sweeps (load -> block reduce -> load -> store
+// serialised per 4-wave block: 2.4 TB/s effective on the 13B step's 14 GB, profiles/r05_cfg5_last_step.txt).  Same bytes out.
+template <int CH>
+__global__ __launch_bounds__(256) void fp8_rowquant_reg_kernel(const bf16* x, long ld, int cols, uint8_t* q,
+                                                               long ldq, float* scale) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const bf16* xr = x + row * ld;
+  const int nch = cols / 8;
+  float v[CH][8];
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = threadIdx.x + 256 * k;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+    if (c < nch) VecIO<bf16>::load(xr + c * 8, v[k]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[k][e]));
+  }
+  m = block_max<256>(m, red);
+  const float sc = m > 0.f ? 448.f / m : 1.f;
+  if (threadIdx.x == 0) scale[row] = m > 0.f ? m / 448.f : 1.f;
+  uint8_t* qr = q + row * ldq;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = threadIdx.x + 256 * k;
+    if (c < nch) *reinterpret_cast<int2*>(qr + c * 8) = fp8_pack8(v[k], sc);
+  }
+}
+
 // ---- per-COLUMN scaled e4m3, TRANSPOSED output (the weight of a grad-input GEMM: dx = dy W reduces
 // over W's ROWS, so the fp8 MFMA wants W^T K-major with one scale per row of W^T = per column of W).
 // pass 1: amax[c] = max_r |x[r, c]| (row slabs, atomicMax on the bit pattern of a non-negative float)
@@ -818,8 +850,19 @@ extern "C" int mk_fp8_quantize_rows(const void* x, int32_t rows, int32_t cols, i
   if (dtype != MK_BF16 || (cols % 8) || (ld % 8) || (ldq % 8) || (reinterpret_cast<uintptr_t>(x) & 15) ||
       (reinterpret_cast<uintptr_t>(q) & 7))
     return MK_ERR_UNSUPPORTED;
-  MK_LAUNCH(fp8_rowquant_kernel, dim3(rows), dim3(256), 0, MK_ST, (const bf16*)x, (long)ld, cols, q,
-            (long)ldq, scales);
+  const int ch = mk_cdiv(cols / 8, 256);
+  static const bool two_pass = getenv("MK_FP8_ROWQUANT_TWO_PASS") != nullptr;       // A/B: the round-3 kernel
+#define MK_RQ(CHV) MK_LAUNCH(fp8_rowquant_reg_kernel<CHV>, dim3(rows), dim3(256), 0, MK_ST, (const bf16*)x, (long)ld, cols, q, \
+                             (long)ldq, scales)
+  if (two_pass || ch > 8)
+    MK_LAUNCH(fp8_rowquant_kernel, dim3(rows), dim3(256), 0, MK_ST, (const bf16*)x, (long)ld, cols, q,
+              (long)ldq, scales);
+  else if (ch <= 1) MK_RQ(1);
+  else if (ch <= 2) MK_RQ(2);
+  else if (ch <= 3) MK_RQ(3);
+  else if (ch <= 4) MK_RQ(4);
+  else MK_RQ(8);
+#undef MK_RQ
   return mk_check_launch();
 }
 
