@@ -539,8 +539,9 @@ def main():
                                           "priced against its own dense peak"} if n8 else {}),
                          # context, not the contract's peak: a register-only MFMA loop sustains 2475 TFLOP/s on all-zero
                          # operands but 1767-1781 on random bf16 data on this part (power-bound; profiles/r06_mfma_power.txt)
-                         "real_data_mfma_ceiling": {"tflops": 1775.0, "frac_of_it": round(achieved / 1775.0e12, 4),
-                                                    "source": "scripts/probe/mfma_power.hip, profiles/r06_mfma_power.txt"},
+                         **({"real_data_mfma_ceiling": {"tflops": 1775.0, "frac_of_it": round(achieved / 1775.0e12, 4),
+                                                        "source": "scripts/probe/mfma_power.hip, profiles/r06_mfma_power.txt"}}
+                            if not n8 else {}),          # (bf16 runs only: the probe measured the bf16 pipe)
                          "whole_step_model_tflops": round(value / world * alg_tf, 1),
                          "whole_step_frac": round(value / world * alg_tf * 1e12 / MFMA_BF16_PEAK, 4),
                          # fused attention kernels (csrc/attention.hip), algorithmic FLOPs (causal =

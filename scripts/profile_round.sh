@@ -92,7 +92,7 @@ fi
 if has parity; then
   # the measured errors of the full-size parity tests (prints of tests/test_fullsize_gpu.py, test_fp8_gpu.py)
   timeout 600 python -m pytest tests/test_fullsize_gpu.py tests/test_fp8_gpu.py -m gpu -q -s -p no:cacheprovider 2>&1 \
-    | grep -E "oracle|yardstick|relative errors|real7b|passed|failed" > $OUT/${R}_fullsize_parity.log
+    | grep -E "oracle|yardstick|relative errors|real7b|REFERENCE|real width|passed|failed" > $OUT/${R}_fullsize_parity.log
 fi
 if has probes; then
   timeout 300 python scripts/probe/gloo_cuda_race.py 150 1 > $OUT/${R}_probe_gloo_cuda_race.txt 2>&1
