@@ -299,6 +299,7 @@ int launch_v7(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t 
 int launch_v8(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st, bool f16);            // gemm_v8.hip
 #endif
 int launch_v9(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st, bool f16);            // gemm_v9.hip
+int v9_mfma16_layouts();                                                                                        // gemm_v9.hip
 }
 
 // y[M <= 16, N] = prologue(x) W^T (+ residual): the linear layers of one decode position per sample
@@ -394,10 +395,16 @@ int pick_cfg(const mk_gemm_desc* d, int nbatch, bool v7_ok, int n_cus) {
   // at K <= 12288 (v9's fixed cost per tile is 14 us against 12.5, its K-tile 1.485 us against 1.54).
   // MK_GEMM_V9: 0 = never, 1 = this policy (default), 2 = wherever it is legal.
   static const int v9_mode = [] { const char* e = getenv("MK_GEMM_V9"); return e ? atoi(e) : 1; }();
+  // (layouts on the 16 x 16 x 32 loop have an all-in-registers epilogue that also takes the residual)
+  const bool m16 = ((mkg::v9_mfma16_layouts() >> layout) & 1) != 0;
   const bool v9_legal = d->dtype != MK_F32 && d->dtype != MK_FP8 && d->M % 256 == 0 && d->N % 256 == 0 && d->K % 64 == 0 &&
-                        full >= 1 && d->bias_mode == 0 && d->act == 0 && !d->R && !d->accumulate && !d->scale_a &&
-                        !d->scale_b;
-  if (v9_legal && (v9_mode == 2 || (v9_mode == 1 && (layout == 3 || layout == 1 || nk >= 256)))) return 15;
+                        full >= 1 && !d->scale_a && !d->scale_b &&
+                        d->bias_mode == 0 && d->act == 0 && !d->accumulate && (m16 || !d->R);
+  // forward (K-major x K-major) on the 16 x 16 x 32 loop, inside the cfg-3 step against v7 (profiles/r06_gemm_v9_mfma16.txt):
+  // q|k|v +2.5 %, gate|up +0.7 %, down +3.3 %, but o_proj (288 tiles, K = 4096) -5 %: v9 runs a tail as a SECOND launch
+  // behind its whole rounds, which one short round of short tiles does not amortise
+  const bool nt16 = m16 && layout == 0 && !(R > 0 && full < 2 && nk < 128);
+  if (v9_legal && (v9_mode == 2 || (v9_mode == 1 && (layout == 3 || layout == 1 || nk >= 256 || nt16)))) return 15;
   return 11;
 }
 }  // namespace
@@ -510,6 +517,10 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
     if ((cfg == 14 || cfg == 15) && fp8) cfg = 11;       // (v8 / v9 have no e4m3 instantiation)
     // v9 (hand-placed K loop, gemm_v9.hip) takes whole 256 x 256 x 64 tiles only
     if (cfg == 15 && (d->M % 256 != 0 || d->N % 256 != 0 || d->K % 64 != 0 || d->K < 128)) cfg = 11;
+    // the layouts of v9 on the 16 x 16 x 32 loop have a register epilogue for alpha (+ residual) only
+    if (cfg == 15 && ((mkg::v9_mfma16_layouts() >> ((d->a_red_major ? 2 : 0) + (d->b_red_major ? 1 : 0))) & 1) &&
+        (d->bias_mode != 0 || d->act != 0 || d->accumulate || d->scale_a || d->scale_b))
+      cfg = 11;
     if (cfg != 0 && cfg != 5 && cfg != 7 && cfg != 11 && cfg != 14 && cfg != 15) cfg = 5;
     if (cfg >= 5 && !v2_ok) cfg = 0;
     if (fp8 && cfg != 5 && cfg != 11) return MK_ERR_UNSUPPORTED;
@@ -607,7 +618,9 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
       return rc;
     }
 #endif
-    if (v9 && g.dp_tiles >= n_cus) {
+    // (the 16 x 16 x 32 layouts' register epilogue moves 8 bytes per lane: C / R must be 8-byte aligned)
+    const bool v9_c_ok = !((mkg::v9_mfma16_layouts() >> ((d->a_red_major ? 2 : 0) + (d->b_red_major ? 1 : 0))) & 1) || g.c_vec >= 1;
+    if (v9 && g.dp_tiles >= n_cus && v9_c_ok) {
       // whole tiles [0, dp_tiles) on v9, one workgroup each; the spatial tail of the last partial round (planned
       // above exactly as for v7: eighths / quarters of the tiles >= dp_tiles) on v7's sub-tile kernels behind it
       // on the same stream (walkers = 0: every workgroup of that launch is a tail workgroup)
@@ -618,7 +631,10 @@ extern "C" int mk_gemm(const mk_gemm_desc* d_in, void* stream) {
       static const bool no_walk9 = getenv("MK_GEMM_NO_WALK") != nullptr;
       const bool plain9 = d->bias_mode == 0 && d->act == 0 && !d->R && !d->accumulate && g.c_vec == 2 && !d->scale_a &&
                           !d->scale_b && g.ablate != 9;
-      if (!no_walk9 && plain9 && nbatch == 1 && n_cus % 8 == 0 && g.dp_tiles > n_cus && g.dp_tiles % n_cus == 0)
+      const int lay9 = (d->a_red_major ? 2 : 0) + (d->b_red_major ? 1 : 0);
+      const bool regepi9 = plain9 || (((mkg::v9_mfma16_layouts() >> lay9) & 1) && g.c_vec >= 1 && d->bias_mode == 0 && d->act == 0 &&
+                                      !d->accumulate && !d->scale_a && !d->scale_b && g.ablate != 9);
+      if (!no_walk9 && regepi9 && nbatch == 1 && n_cus % 8 == 0 && g.dp_tiles > n_cus && g.dp_tiles % n_cus == 0)
         gmain.x = n_cus;
       int rc = mkg::launch_v9(g, d->a_red_major != 0, d->b_red_major != 0, gmain, st, f16);
       if (rc == MK_OK && tail_wgs > 0) {

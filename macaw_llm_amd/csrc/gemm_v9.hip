@@ -38,6 +38,15 @@
 #undef MK_V9_SFX
 
 namespace mkg {
+// layouts whose K loop runs on 16 x 16 x 32 MFMAs with the all-in-registers epilogue (any epilogue, walking allowed):
+// bit 0 = K-major x K-major (scripts/gen_v9_loop.py --mfma16)
+int v9_mfma16_layouts() {
+#ifdef V9_MFMA16
+  return 1;
+#else
+  return 0;
+#endif
+}
 int launch_v9(const GemmArgs& g, bool a_red, bool b_red, dim3 grid, hipStream_t st, bool f16) {
   if (f16) {
     if (!a_red && !b_red) return e_f16::launch_v9<false, false>(g, grid, st);

@@ -22,6 +22,7 @@ import sys
 
 # timing-only ablations for experiment builds (scripts/probe/build_v9_variants.sh); the shipped text has none set
 NO_DMA = NO_READ = NO_BAR = False
+MFMA16 = True       # layout 00 on v_mfma_f32_16x16x32 (round 6: K-tile 1.50 -> 1.38 us, profiles/r06_gemm_v9_mfma16.txt); --no-mfma16 = round 5's file
 
 HALF = 16384
 SLOT = 32768
@@ -227,6 +228,183 @@ def prologue(e, a_red, b_red, walk=False):
         e(r)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# EXPERIMENT (--mfma16, round 6): the K-major x K-major loop on v_mfma_f32_16x16x32_* -- the shape every vendor kernel
+# uses (profiles/r06_vendor_isa.txt) and the one that draws 4 % less power per FLOP (profiles/r06_mfma_power.txt).
+# Same tile, same LDS image, same LDS-DMA stream, same slot / wait protocol; per K-tile 128 MFMAs of 16 cycles in four
+# QUARTERS of 32 (quarter q = B fragments 4 (q & 1) .. + 3 of k32-step q >> 1, all 8 A fragments), 32 ds_read_b128.
+# Register map:  a[(8 i + j) * 4 ..] fragment (i, j) of 16 x 16;  set s: A fragments v[64 s + 4 i ..], B fragments
+# v[64 s + 32 + 4 j ..];  v[128:135] / v[136:143] LDS-DMA voffsets of A / B;  v[144:145] / v[148:149] LDS read addresses
+# of A / B per k32-step (the swizzle depends on it: + (1 << 6)); fragments of 16 rows are + 2048 apart.
+SA16, SB16 = [0, 64], [32, 96]
+VOA16, VOB16, ADA16, ADB16 = 128, 136, 144, 148
+
+
+def reads16(s, h, first=None):
+    """the 16 fragment reads of k32-step h into set s: A0..A7 then B0..B7 (quarter 2 q needs every A fragment and B 0..3)"""
+    out = [f"ds_read_b128 v[{SA16[s] + 4 * f}:{SA16[s] + 4 * f + 3}], v{ADA16 + h}" + (f" offset:{f * 2048}" if f else "")
+           for f in range(8)]
+    out += [f"ds_read_b128 v[{SB16[s] + 4 * f}:{SB16[s] + 4 * f + 3}], v{ADB16 + h}" + (f" offset:{f * 2048}" if f else "")
+            for f in range(8)]
+    return out
+
+
+def mfmas16(s, q):
+    out = []
+    for j in range(4 * (q & 1), 4 * (q & 1) + 4):
+        for i in range(8):
+            acc = (8 * i + j) * 4
+            out.append(f"v_mfma_f32_16x16x32_@SFX@ a[{acc}:{acc + 3}], v[{SB16[s] + 4 * j}:{SB16[s] + 4 * j + 3}], "
+                       f"v[{SA16[s] + 4 * i}:{SA16[s] + 4 * i + 3}], a[{acc}:{acc + 3}]")
+    return out
+
+
+def quarter(e, q, reads, dma, salu, valu, wait, tail_salu=()):
+    """32 MFMAs (two per 32-cycle slot); the fillers of slot g follow its two MFMAs split between them.  Slots as in
+    `kstep`: reads from slot 0 on (one or two per slot), LDS-DMA pieces in slots 8 .. 15, SALU in slots 0 .. 7, VALU from 8"""
+    slots = [[] for _ in range(16)]
+    if NO_READ:
+        reads = []
+    if NO_DMA:
+        dma = []
+    per = (len(reads) + 15) // 16 if reads else 0
+    for k, r in enumerate(reads):
+        slots[k // per if len(reads) > 8 else k].append(r)
+    for k, (m0w, ld) in enumerate(dma):
+        slots[8 + 2 * k].append(m0w)
+        slots[9 + 2 * k].append(ld)
+    for g, ins in enumerate(salu):
+        slots[g].append(ins)
+    g = 8
+    for ins in valu:
+        slots[g].append(ins)
+        g += 1
+    for ins in tail_salu:
+        slots[15].append(ins)
+    ms = mfmas16(q >> 1, q)
+    if wait:
+        e("s_waitcnt lgkmcnt(0)")
+    for g in range(16):
+        parts = [p for ins in slots[g] for p in ins.split(" ; ")]
+        assert len(slots[g]) <= 4, (q, g, slots[g])
+        # an M0 write and its load stay in different slots; SCC chains stay adjacent (they are one entry): split only
+        # between entries
+        half = (len(slots[g]) + 1) // 2
+        first = [p for ins in slots[g][:half] for p in ins.split(" ; ")]
+        second = [p for ins in slots[g][half:] for p in ins.split(" ; ")]
+        e(ms[2 * g])
+        for p in first:
+            e(p)
+        e(ms[2 * g + 1])
+        for p in second:
+            e(p)
+        del parts
+
+
+def dma_group16(op, vo_base, soff):
+    rs = "%[rsA]" if op == "A" else "%[rsB]"
+    out = []
+    for i in range(4):
+        m0w = f"s_add_u32 m0, s69, {i * 4096}" if i else "s_mov_b32 m0, s69"
+        out.append((m0w, f"buffer_load_dwordx4 v{vo_base + i}, {rs}, {soff} offen lds"))
+    return out
+
+
+def body16(e, mode):
+    nxt = mode != "LAST"
+    full = mode == "FULL"
+    # quarter 0 (set 0, B 0..3): reads A0..A7 of k32-step 1 -> set 1; LDS-DMA B(T + 1) half 1
+    salu = []
+    if nxt:
+        salu += ["s_add_u32 s70, s64, 0x8000 ; s_cmp_eq_u32 s70, 0x18000 ; s_cselect_b32 s70, 0, s70",
+                 "s_xor_b32 s72, s65, 0x8000",
+                 "s_sub_u32 s75, s67, %[stB]",
+                 "s_add_u32 s69, %[wv], s72",
+                 f"s_add_u32 s69, s69, {B_BASE + HALF}",
+                 "s_sub_u32 s73, s70, s64",
+                 "s_sub_u32 s74, s72, s65"]
+    if full:
+        salu += ["s_sub_u32 s71, s64, 0x8000 ; s_cmp_eq_u32 s64, 0 ; s_cselect_b32 s71, 0x10000, s71"]
+    r1 = reads16(1, 1)
+    quarter(e, 0, r1[:8], dma_group16("B", VOB16 + 4, "s75") if nxt else [], salu, [], wait=True)
+    # quarter 1 (set 0, B 4..7): reads B0..B7 of k32-step 1 -> set 1; LDS-DMA A(T + 2) half 0
+    if full:
+        e("s_add_u32 s69, %[wv], s71")
+    quarter(e, 1, r1[8:], dma_group16("A", VOA16, "s66") if full else [], [], [], wait=False)
+    # quarter 2 (set 1, B 0..3): LDS-DMA A(T + 2) half 1; the read addresses move to tile T + 1
+    if full:
+        e(f"s_add_u32 s69, s69, {HALF}")
+    valu = []
+    if nxt:
+        valu = [f"v_add_u32 v{ADA16 + k}, s73, v{ADA16 + k}" for k in range(2)] + \
+               [f"v_add_u32 v{ADB16 + k}, s74, v{ADB16 + k}" for k in range(2)]
+    quarter(e, 2, [], dma_group16("A", VOA16 + 4, "s66") if full else [], [], valu, wait=True)
+    if nxt:
+        e("s_waitcnt vmcnt(8) lgkmcnt(0)" if full else "s_waitcnt vmcnt(0) lgkmcnt(0)")
+        if not NO_BAR:
+            e("s_barrier")
+        e("s_add_u32 s69, %[wv], s65")
+        e(f"s_add_u32 s69, s69, {B_BASE}")
+    # quarter 3 (set 1, B 4..7): all 16 reads of k32-step 0 of tile T + 1 -> set 0; LDS-DMA B(T + 2) half 0
+    salu = ["s_mov_b32 s64, s70", "s_mov_b32 s65, s72"] if nxt else []
+    tail = ["s_add_u32 s66, s66, %[stA]", "s_add_u32 s67, s67, %[stB]"] if nxt else []
+    quarter(e, 3, reads16(0, 0) if nxt else [], dma_group16("B", VOB16, "s67") if full else [], salu, [], wait=False,
+            tail_salu=tail)
+
+
+def prologue16(e, walk):
+    e(f"v_mov_b32 v{VOA16}, %[voA]")
+    e(f"v_mov_b32 v{VOB16}, %[voB]")
+    for op, vo in (("A", VOA16), ("B", VOB16)):
+        st = f"%[i{op}]"
+        for i in range(1, 8):
+            e(f"v_add_u32 v{vo + i}, {st}, v{vo + i - 1}")
+    for op, ad in (("A", ADA16), ("B", ADB16)):
+        e(f"v_mov_b32 v{ad}, %[ad{op}]")
+        e(f"v_xor_b32 v{ad + 1}, 0x40, v{ad}")
+    e("s_mov_b32 s64, 0")
+    e("s_mov_b32 s65, 0")
+    e("s_lshl_b32 s66, %[stA], 1")
+    e("s_lshl_b32 s67, %[stB], 1")
+    e("s_sub_u32 s68, %[nk], 2")
+    for r in range(256):
+        e(f"v_accvgpr_write_b32 a{r}, 0")
+    e("s_waitcnt vmcnt(0)" if walk else "s_waitcnt vmcnt(12)")
+    e("s_barrier")
+    for r in reads16(0, 0):
+        e(r)
+
+
+def loop_text16(walk=False):
+    e = Emit()
+    prologue16(e, walk)
+    e("s_cmp_eq_u32 s68, 0")
+    e("s_cbranch_scc1 .Lv9n%=")
+    e(".p2align 6")
+    e(".Lv9l%=:")
+    body16(e, "FULL")
+    e("s_sub_u32 s68, s68, 1")
+    e("s_cmp_lg_u32 s68, 0")
+    e("s_cbranch_scc1 .Lv9l%=")
+    e(".Lv9n%=:")
+    body16(e, "NEXT")
+    body16(e, "LAST")
+    e("s_nop 15")
+    e("s_nop 15")
+    return e.lines
+
+
+def acc_read_macros16():
+    out = []
+    for i in range(8):
+        for j in range(8):
+            base = (8 * i + j) * 4
+            txt = "".join(f"v_accvgpr_read_b32 %{e}, a{base + e}\\n\\t" for e in range(4))
+            outs = ", ".join(f'"=v"((X)[{e}])' for e in range(4))
+            out.append(f"#define V9_ACC16_READ_{i}_{j}(X) asm volatile(\"{txt}\" : {outs})")
+    return "\n".join(out)
+
+
 def loop_text(a_red, b_red, walk=False):
     e = Emit()
     prologue(e, a_red, b_red, walk)
@@ -295,6 +473,16 @@ def main(path):
                 lines = loop_text(bool(a_red), bool(b_red), walk)
                 order_ok(lines)
                 parts.append(f"#define V9_LOOP_TEXT_{a_red}{b_red}{'_W' if walk else ''} \\\n" + c_string(lines))
+    if MFMA16:
+        parts.append("#define V9_MFMA16 1")
+        for walk in (False, True):
+            lines = loop_text16(walk)
+            order_ok(lines)
+            parts.append(f"#define V9_LOOP16_TEXT_00{'_W' if walk else ''} \\\n" + c_string(lines))
+        clob16 = ", ".join([f'"v{r}"' for r in range(152)] + [f'"a{r}"' for r in range(256)] +
+                           [f'"s{r}"' for r in range(64, 76)] + ['"scc"', '"memory"'])
+        parts.append(f"#define V9_LOOP16_CLOBBERS {clob16}")
+        parts.append(acc_read_macros16())
     clob = ", ".join([f'"v{r}"' for r in range(88)] + [f'"a{r}"' for r in range(256)] +
                      [f'"s{r}"' for r in range(64, 76)] + ['"scc"', '"memory"'])
     parts.append(f"#define V9_LOOP_CLOBBERS {clob}")
@@ -316,6 +504,10 @@ if __name__ == "__main__":
             NO_READ = True
         elif a == "--nobar":
             NO_BAR = True
+        elif a == "--mfma16":
+            MFMA16 = True
+        elif a == "--no-mfma16":
+            MFMA16 = False
         elif a.startswith("--"):
             sys.exit(f"unknown option {a}")
     main(args[0] if args else "macaw_llm_amd/csrc/gemm_v9_loop.inc")

@@ -9,7 +9,7 @@ F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-result -m
 build() {   # name, generator options...
   name=$1; shift
   X=""
-  if [ "$name" = noepi ]; then X="-DMK_V9_NOEPI"; fi
+  if [ "$name" = noepi ] || [ "$name" = mfma16_noepi ]; then X="-DMK_V9_NOEPI"; fi
   if [ "$name" = nostore ]; then X="-DMK_EPI_NOSTORE"; fi
   out=$root/scripts/probe/_probe_v9_$name
   mkdir -p $out/src
@@ -30,6 +30,8 @@ for v in "$@"; do
     nobar) build nobar --nobar & ;;
     noepi) build noepi & ;;
     nostore) build nostore & ;;
+    mfma16) build mfma16 --mfma16 & ;;                  # round 6: layout NT on v_mfma_f32_16x16x32 (CORRECT results)
+    mfma16_noepi) build mfma16_noepi --mfma16 & ;;      # ... timing-only, no epilogue (K-slope against `noepi`)
     *) echo "unknown variant $v"; exit 1 ;;
   esac
 done
