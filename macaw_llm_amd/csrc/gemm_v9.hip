@@ -39,10 +39,10 @@
 
 namespace mkg {
 // layouts whose K loop runs on 16 x 16 x 32 MFMAs with the all-in-registers epilogue (any epilogue, walking allowed):
-// bit 0 = K-major x K-major (scripts/gen_v9_loop.py --mfma16)
+// bit (2 a_red + b_red) (scripts/gen_v9_loop.py)
 int v9_mfma16_layouts() {
 #ifdef V9_MFMA16
-  return 1;
+  return V9_MFMA16;
 #else
   return 0;
 #endif

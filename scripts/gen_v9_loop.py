@@ -22,7 +22,8 @@ import sys
 
 # timing-only ablations for experiment builds (scripts/probe/build_v9_variants.sh); the shipped text has none set
 NO_DMA = NO_READ = NO_BAR = False
-MFMA16 = True       # layout 00 on v_mfma_f32_16x16x32 (round 6: K-tile 1.50 -> 1.38 us, profiles/r06_gemm_v9_mfma16.txt); --no-mfma16 = round 5's file
+MFMA16 = 15         # bit mask of the layouts (2 a_red + b_red) whose loop runs on v_mfma_f32_16x16x32 (round 6: K-tile 1.50 ->
+                    # 1.38 us, profiles/r06_gemm_v9_mfma16.txt); --mfma16=<mask>, --no-mfma16 = round 5's file
 
 HALF = 16384
 SLOT = 32768
@@ -237,15 +238,24 @@ def prologue(e, a_red, b_red, walk=False):
 # v[64 s + 32 + 4 j ..];  v[128:135] / v[136:143] LDS-DMA voffsets of A / B;  v[144:145] / v[148:149] LDS read addresses
 # of A / B per k32-step (the swizzle depends on it: + (1 << 6)); fragments of 16 rows are + 2048 apart.
 SA16, SB16 = [0, 64], [32, 96]
-VOA16, VOB16, ADA16, ADB16 = 128, 136, 144, 148
+VOA16, VOB16, ADA16, ADB16 = 128, 136, 144, 152       # 8 read-address registers per operand (a K-major one uses 2)
+NV16 = 160                                            # VGPRs of the asm block: v[0:159]
 
 
-def reads16(s, h, first=None):
-    """the 16 fragment reads of k32-step h into set s: A0..A7 then B0..B7 (quarter 2 q needs every A fragment and B 0..3)"""
-    out = [f"ds_read_b128 v[{SA16[s] + 4 * f}:{SA16[s] + 4 * f + 3}], v{ADA16 + h}" + (f" offset:{f * 2048}" if f else "")
-           for f in range(8)]
-    out += [f"ds_read_b128 v[{SB16[s] + 4 * f}:{SB16[s] + 4 * f + 3}], v{ADB16 + h}" + (f" offset:{f * 2048}" if f else "")
-            for f in range(8)]
+def frag_reads16(red, set_base, ad, h):
+    """the reads of the 8 fragments (16 rows x 32 k) of k32-step h of one operand.  K-major: one ds_read_b128 each, address
+    register ad + h, fragments + 2048 apart.  Reduction-major: two transposing reads each (k rows + 0 .. 3, + 4 .. 7 of the
+    lane's group of 8), address register ad + f (f = 2 a + b: the swizzle of the image depends on both bits), k32-steps
+    + 8192 apart"""
+    out = []
+    for f in range(8):
+        r = set_base + 4 * f
+        if not red:
+            out.append(f"ds_read_b128 v[{r}:{r + 3}], v{ad + h}" + (f" offset:{f * 2048}" if f else ""))
+        else:
+            off = h * 8192
+            out.append(f"ds_read_b64_tr_b16 v[{r}:{r + 1}], v{ad + f}" + (f" offset:{off}" if off else ""))
+            out.append(f"ds_read_b64_tr_b16 v[{r + 2}:{r + 3}], v{ad + f} offset:{off + 1024}")
     return out
 
 
@@ -260,8 +270,10 @@ def mfmas16(s, q):
 
 
 def quarter(e, q, reads, dma, salu, valu, wait, tail_salu=()):
-    """32 MFMAs (two per 32-cycle slot); the fillers of slot g follow its two MFMAs split between them.  Slots as in
-    `kstep`: reads from slot 0 on (one or two per slot), LDS-DMA pieces in slots 8 .. 15, SALU in slots 0 .. 7, VALU from 8"""
+    """32 MFMAs = 16 slots of two; the fillers of a slot are split between its two MFMAs.  Reads are spread evenly over the
+    16 slots (<= 2 per slot), LDS-DMA pieces sit in slots 8 .. 15 (M0 write, then the load in the next slot), SALU entries
+    in slots 0 .. 7 (an SCC chain is ONE entry and stays adjacent), VALU entries one per slot from slot 0 on when the quarter
+    has no reads, else from slot 8; `tail_salu` goes behind everything else of slot 15."""
     slots = [[] for _ in range(16)]
     if NO_READ:
         reads = []
@@ -269,15 +281,16 @@ def quarter(e, q, reads, dma, salu, valu, wait, tail_salu=()):
         dma = []
     per = (len(reads) + 15) // 16 if reads else 0
     for k, r in enumerate(reads):
-        slots[k // per if len(reads) > 8 else k].append(r)
+        slots[k // per].append(r)
     for k, (m0w, ld) in enumerate(dma):
         slots[8 + 2 * k].append(m0w)
         slots[9 + 2 * k].append(ld)
+    assert len(salu) <= 8
     for g, ins in enumerate(salu):
         slots[g].append(ins)
-    g = 8
+    g = 0 if not reads else 8
     for ins in valu:
-        slots[g].append(ins)
+        slots[g % 16].append(ins)
         g += 1
     for ins in tail_salu:
         slots[15].append(ins)
@@ -285,20 +298,16 @@ def quarter(e, q, reads, dma, salu, valu, wait, tail_salu=()):
     if wait:
         e("s_waitcnt lgkmcnt(0)")
     for g in range(16):
-        parts = [p for ins in slots[g] for p in ins.split(" ; ")]
-        assert len(slots[g]) <= 4, (q, g, slots[g])
-        # an M0 write and its load stay in different slots; SCC chains stay adjacent (they are one entry): split only
-        # between entries
+        assert len(slots[g]) <= (6 if g == 15 else 4), (q, g, slots[g])
         half = (len(slots[g]) + 1) // 2
-        first = [p for ins in slots[g][:half] for p in ins.split(" ; ")]
-        second = [p for ins in slots[g][half:] for p in ins.split(" ; ")]
         e(ms[2 * g])
-        for p in first:
-            e(p)
+        for ins in slots[g][:half]:
+            for part in ins.split(" ; "):
+                e(part)
         e(ms[2 * g + 1])
-        for p in second:
-            e(p)
-        del parts
+        for ins in slots[g][half:]:
+            for part in ins.split(" ; "):
+                e(part)
 
 
 def dma_group16(op, vo_base, soff):
@@ -310,10 +319,12 @@ def dma_group16(op, vo_base, soff):
     return out
 
 
-def body16(e, mode):
+def body16(e, a_red, b_red, mode):
+    """one K-tile T in four quarters.  Quarter q computes B fragments 4 (q & 1) .. + 3 x all A fragments of k32-step q >> 1
+    out of register set q >> 1.  Reads: quarter 0 fetches A, quarter 1 B of k32-step 1 into set 1; quarter 3 (behind the
+    tile's barrier) all of k32-step 0 of tile T + 1 into set 0.  LDS-DMA groups and the slot arithmetic as in `body`."""
     nxt = mode != "LAST"
     full = mode == "FULL"
-    # quarter 0 (set 0, B 0..3): reads A0..A7 of k32-step 1 -> set 1; LDS-DMA B(T + 1) half 1
     salu = []
     if nxt:
         salu += ["s_add_u32 s70, s64, 0x8000 ; s_cmp_eq_u32 s70, 0x18000 ; s_cselect_b32 s70, 0, s70",
@@ -325,19 +336,18 @@ def body16(e, mode):
                  "s_sub_u32 s74, s72, s65"]
     if full:
         salu += ["s_sub_u32 s71, s64, 0x8000 ; s_cmp_eq_u32 s64, 0 ; s_cselect_b32 s71, 0x10000, s71"]
-    r1 = reads16(1, 1)
-    quarter(e, 0, r1[:8], dma_group16("B", VOB16 + 4, "s75") if nxt else [], salu, [], wait=True)
-    # quarter 1 (set 0, B 4..7): reads B0..B7 of k32-step 1 -> set 1; LDS-DMA A(T + 2) half 0
+    quarter(e, 0, frag_reads16(a_red, SA16[1], ADA16, 1), dma_group16("B", VOB16 + 4, "s75") if nxt else [], salu, [],
+            wait=True)
     if full:
         e("s_add_u32 s69, %[wv], s71")
-    quarter(e, 1, r1[8:], dma_group16("A", VOA16, "s66") if full else [], [], [], wait=False)
-    # quarter 2 (set 1, B 0..3): LDS-DMA A(T + 2) half 1; the read addresses move to tile T + 1
+    quarter(e, 1, frag_reads16(b_red, SB16[1], ADB16, 1), dma_group16("A", VOA16, "s66") if full else [], [], [],
+            wait=False)
     if full:
         e(f"s_add_u32 s69, s69, {HALF}")
     valu = []
-    if nxt:
-        valu = [f"v_add_u32 v{ADA16 + k}, s73, v{ADA16 + k}" for k in range(2)] + \
-               [f"v_add_u32 v{ADB16 + k}, s74, v{ADB16 + k}" for k in range(2)]
+    if nxt:     # the read addresses move to tile T + 1's slots (their last reads of tile T were issued in quarters 0 / 1)
+        valu = [f"v_add_u32 v{ADA16 + k}, s73, v{ADA16 + k}" for k in range(8 if a_red else 2)] + \
+               [f"v_add_u32 v{ADB16 + k}, s74, v{ADB16 + k}" for k in range(8 if b_red else 2)]
     quarter(e, 2, [], dma_group16("A", VOA16 + 4, "s66") if full else [], [], valu, wait=True)
     if nxt:
         e("s_waitcnt vmcnt(8) lgkmcnt(0)" if full else "s_waitcnt vmcnt(0) lgkmcnt(0)")
@@ -345,23 +355,33 @@ def body16(e, mode):
             e("s_barrier")
         e("s_add_u32 s69, %[wv], s65")
         e(f"s_add_u32 s69, s69, {B_BASE}")
-    # quarter 3 (set 1, B 4..7): all 16 reads of k32-step 0 of tile T + 1 -> set 0; LDS-DMA B(T + 2) half 0
     salu = ["s_mov_b32 s64, s70", "s_mov_b32 s65, s72"] if nxt else []
     tail = ["s_add_u32 s66, s66, %[stA]", "s_add_u32 s67, s67, %[stB]"] if nxt else []
-    quarter(e, 3, reads16(0, 0) if nxt else [], dma_group16("B", VOB16, "s67") if full else [], salu, [], wait=False,
-            tail_salu=tail)
+    reads = (frag_reads16(a_red, SA16[0], ADA16, 0) + frag_reads16(b_red, SB16[0], ADB16, 0)) if nxt else []
+    quarter(e, 3, reads, dma_group16("B", VOB16, "s67") if full else [], salu, [], wait=False, tail_salu=tail)
 
 
-def prologue16(e, walk):
+def prologue16(e, a_red, b_red, walk):
     e(f"v_mov_b32 v{VOA16}, %[voA]")
     e(f"v_mov_b32 v{VOB16}, %[voB]")
-    for op, vo in (("A", VOA16), ("B", VOB16)):
+    for op, vo, red in (("A", VOA16, a_red), ("B", VOB16, b_red)):
         st = f"%[i{op}]"
-        for i in range(1, 8):
+        for i in range(1, 4):
             e(f"v_add_u32 v{vo + i}, {st}, v{vo + i - 1}")
-    for op, ad in (("A", ADA16), ("B", ADB16)):
+        if not red:                       # h = 1: 128 rows further = four piece strides
+            e(f"v_add_u32 v{vo + 4}, {st}, v{vo + 3}")
+            for i in range(1, 4):
+                e(f"v_add_u32 v{vo + 4 + i}, {st}, v{vo + 3 + i}")
+        else:                             # h = 1: 128 columns further = 256 bytes
+            for i in range(4):
+                e(f"v_add_u32 v{vo + 4 + i}, 0x100, v{vo + i}")
+    for op, ad, red in (("A", ADA16, a_red), ("B", ADB16, b_red)):
         e(f"v_mov_b32 v{ad}, %[ad{op}]")
-        e(f"v_xor_b32 v{ad + 1}, 0x40, v{ad}")
+        if not red:
+            e(f"v_xor_b32 v{ad + 1}, 0x40, v{ad}")                      # k32-step 1: 16-byte chunk + 4
+        else:
+            for f in range(1, 8):                                      # fragment f = 2 a + b: chunk ^ (4 a + 2 b)
+                e(f"v_xor_b32 v{ad + f}, {hex(((f >> 1) << 6) | ((f & 1) << 5))}, v{ad}")
     e("s_mov_b32 s64, 0")
     e("s_mov_b32 s65, 0")
     e("s_lshl_b32 s66, %[stA], 1")
@@ -371,24 +391,24 @@ def prologue16(e, walk):
         e(f"v_accvgpr_write_b32 a{r}, 0")
     e("s_waitcnt vmcnt(0)" if walk else "s_waitcnt vmcnt(12)")
     e("s_barrier")
-    for r in reads16(0, 0):
+    for r in frag_reads16(a_red, SA16[0], ADA16, 0) + frag_reads16(b_red, SB16[0], ADB16, 0):
         e(r)
 
 
-def loop_text16(walk=False):
+def loop_text16(a_red, b_red, walk=False):
     e = Emit()
-    prologue16(e, walk)
+    prologue16(e, a_red, b_red, walk)
     e("s_cmp_eq_u32 s68, 0")
     e("s_cbranch_scc1 .Lv9n%=")
     e(".p2align 6")
     e(".Lv9l%=:")
-    body16(e, "FULL")
+    body16(e, a_red, b_red, "FULL")
     e("s_sub_u32 s68, s68, 1")
     e("s_cmp_lg_u32 s68, 0")
     e("s_cbranch_scc1 .Lv9l%=")
     e(".Lv9n%=:")
-    body16(e, "NEXT")
-    body16(e, "LAST")
+    body16(e, a_red, b_red, "NEXT")
+    body16(e, a_red, b_red, "LAST")
     e("s_nop 15")
     e("s_nop 15")
     return e.lines
@@ -470,16 +490,23 @@ def main(path):
     for a_red in (0, 1):
         for b_red in (0, 1):
             for walk in (False, True):
+                if (MFMA16 >> (2 * a_red + b_red)) & 1:     # this layout runs on the 16 x 16 x 32 loop below
+                    parts.append(f"#define V9_LOOP_TEXT_{a_red}{b_red}{'_W' if walk else ''} \"\"")
+                    continue
                 lines = loop_text(bool(a_red), bool(b_red), walk)
                 order_ok(lines)
                 parts.append(f"#define V9_LOOP_TEXT_{a_red}{b_red}{'_W' if walk else ''} \\\n" + c_string(lines))
     if MFMA16:
-        parts.append("#define V9_MFMA16 1")
-        for walk in (False, True):
-            lines = loop_text16(walk)
-            order_ok(lines)
-            parts.append(f"#define V9_LOOP16_TEXT_00{'_W' if walk else ''} \\\n" + c_string(lines))
-        clob16 = ", ".join([f'"v{r}"' for r in range(152)] + [f'"a{r}"' for r in range(256)] +
+        parts.append(f"#define V9_MFMA16 {MFMA16}      // bit (2 a_red + b_red): this layout's K loop is the 16 x 16 x 32 one")
+        for a_red in (0, 1):
+            for b_red in (0, 1):
+                if not (MFMA16 >> (2 * a_red + b_red)) & 1:
+                    continue
+                for walk in (False, True):
+                    lines = loop_text16(bool(a_red), bool(b_red), walk)
+                    order_ok(lines)
+                    parts.append(f"#define V9_LOOP16_TEXT_{a_red}{b_red}{'_W' if walk else ''} \\\n" + c_string(lines))
+        clob16 = ", ".join([f'"v{r}"' for r in range(NV16)] + [f'"a{r}"' for r in range(256)] +
                            [f'"s{r}"' for r in range(64, 76)] + ['"scc"', '"memory"'])
         parts.append(f"#define V9_LOOP16_CLOBBERS {clob16}")
         parts.append(acc_read_macros16())
@@ -504,10 +531,10 @@ if __name__ == "__main__":
             NO_READ = True
         elif a == "--nobar":
             NO_BAR = True
-        elif a == "--mfma16":
-            MFMA16 = True
+        elif a.startswith("--mfma16"):
+            MFMA16 = int(a.split("=")[1]) if "=" in a else 15
         elif a == "--no-mfma16":
-            MFMA16 = False
+            MFMA16 = 0
         elif a.startswith("--"):
             sys.exit(f"unknown option {a}")
     main(args[0] if args else "macaw_llm_amd/csrc/gemm_v9_loop.inc")

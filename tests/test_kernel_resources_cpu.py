@@ -129,6 +129,6 @@ def test_no_compiler_code_touches_the_hand_placed_gemms_accumulator_registers():
             elif op == "v_accvgpr_read_b32":
                 reads[int(areg.search(ins).group(1))] += 1
             else:
-                assert op.startswith("v_mfma_f32_32x32x16_"), (sym, ins)   # no ds_read / buffer_load / v_mov into an AGPR
+                assert op.startswith(("v_mfma_f32_32x32x16_", "v_mfma_f32_16x16x32_")), (sym, ins)   # no ds_read / buffer_load / v_mov into an AGPR
         assert ops["v_accvgpr_write_b32"] == 512 and ops["v_accvgpr_read_b32"] == 512, (sym, dict(ops))
         assert sorted(reads) == list(range(256)) and set(reads.values()) == {2}, sym
