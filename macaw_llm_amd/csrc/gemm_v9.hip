@@ -13,6 +13,14 @@
 // barrier -- every one of them assigned to an MFMA gap, at most four per gap, the M0 write of a piece one gap
 // ahead of its load, no wait inside a k-step.
 //
+// Round 6: the loops run on v_mfma_f32_16x16x32 (V9_MFMA16 bit mask in the generated file: all four layouts): per K-tile
+// and wave 128 MFMAs of 16 cycles in four quarters (quarter q = B fragments 4 (q & 1) .. + 3 x all eight A fragments of
+// k32-step q >> 1), the same 32 ds_read_b128 / 64 transposing reads, the same LDS-DMA stream and slot / wait protocol.
+// It is the MFMA shape of every vendor kernel for these shapes (profiles/r06_vendor_isa.txt) and it draws less power per
+// FLOP (profiles/r06_mfma_power.txt): 1.50 -> 1.38 us per K-tile, 11.4 -> 9.4 us fixed, bit-identical results
+// (profiles/r06_gemm_v9_mfma16.txt).  The accumulator layout (a lane owns 4 consecutive columns of one row) gives an
+// all-in-registers epilogue of 8-byte accesses for alpha (+ residual).
+//
 // Whole tiles only (M % 256 == N % 256 == 0, K % 64 == 0): the launcher in gemm.hip sends everything else to v7.
 //
 // Replaces the nn.Linear matmuls of /root/reference/modeling.py:134-140,159-162,597 and their gradients (same

@@ -17,6 +17,10 @@ Register map of the asm block (fixed physical registers, all in the clobber list
   v[80:83]   LDS read addresses of A (K-major: per k-step; reduction-major: per fragment), v[84:87] of B
   s64 aoff (A slot of tile T: 0 / 32 Ki / 64 Ki)   s65 boff (0 / 32 Ki)   s66 kA2   s67 kB2 (K-tile byte offsets of T + 2)
   s68 loop counter   s69 M0 base of the current piece group   s70 a1off   s71 a2off   s72 bnext   s73 dA   s74 dB   s75 kB1
+
+Round 6: the loops that ship run on v_mfma_f32_16x16x32 (MFMA16 mask; functions *16 below: `loop_text16`, `body16`, `quarter`);
+the round-5 loops on v_mfma_f32_32x32x16 (`loop_text`, `body`, `kstep`) are still generated with --no-mfma16 and still
+simulated by the tests.
 """
 import sys
 

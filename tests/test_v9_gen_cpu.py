@@ -9,6 +9,10 @@
     last read of its previous content, every piece of every K-tile is requested exactly once, and the scalar
     protocol (M0 one instruction ahead of its load, SCC pairs adjacent) is respected.
 
+Round 6: the shipped loops run on v_mfma_f32_16x16x32 (gen.loop_text16: 128 MFMAs per K-tile in four quarters, new
+fragment addressing, one more swizzle bit in the reduction-major image); the identities and the simulation are repeated for
+them at the end of this file.  The round-5 loops (gen.loop_text, `--no-mfma16`) stay in the generator and stay tested.
+
 No GPU involved: the numerics are covered by tests/test_kernels_gpu.py::test_gemm_v9_*."""
 import importlib.util
 import os
@@ -82,8 +86,12 @@ HALF, SLOT, B_BASE = 16384, 32768, 98304
 
 
 class Sim:
-    def __init__(self, a_red, b_red, nk, w=0):
+    def __init__(self, a_red, b_red, nk, w=0, m16=False):
         self.a_red, self.b_red, self.nk, self.w = a_red, b_red, nk, w
+        # register map of the stream being simulated: round 5's 32 x 32 x 16 loop or the 16 x 16 x 32 one
+        self.m16 = m16
+        self.ada, self.adb = (gen.ADA16, gen.ADB16) if m16 else (gen.ADA, gen.ADB)
+        self.voa, self.vob = (gen.VOA16, gen.VOB16) if m16 else (gen.VOA, gen.VOB)
         self.stA = 4096 if a_red else 128        # bytes per K-tile (any distinct positive numbers do)
         self.stB = 8192 if b_red else 128
         self.s = {}
@@ -214,14 +222,22 @@ class Sim:
                 self.last_read[hs] = self.t
                 is_a = addr < B_BASE
                 red = self.a_red if is_a else self.b_red
-                which = addr_reg - (gen.ADA if is_a else gen.ADB)
-                rel = addr % HALF
-                if not red:
-                    ks, frag = which, off // 4096
-                    assert rel // 4096 == frag or True
+                which = addr_reg - (self.ada if is_a else self.adb)
+                if self.m16:
+                    # K-major: address register = k32-step, fragments + 2048; reduction-major: address register =
+                    # fragment, k32-steps + 8192, the second transposing read + 1024
+                    assert 0 <= which < (8 if red else 2), l
+                    if not red:
+                        ks, frag, part = which, off // 2048, 0
+                        assert off % 2048 == 0 and frag < 8
+                    else:
+                        frag, ks, part = which, off // 8192, off % 8192
+                        assert part in (0, 1024) and ks < 2
+                    tag = ("A" if is_a else "B", e["tile"], ks, frag, part)
+                elif not red:
+                    tag = ("A" if is_a else "B", e["tile"], which, off // 4096, 0)
                 else:
-                    frag, ks = which, (off % 4096 >= 0) and (off // 4096)
-                tag = ("A" if is_a else "B", e["tile"], ks, frag, off % 4096 if red else 0)
+                    tag = ("A" if is_a else "B", e["tile"], off // 4096, which, off % 4096)
                 for rr in range(r0, r1 + 1):
                     self.regs.pop(rr, None)
                 self.lgkm.append((r0, r1 - r0 + 1, tag))
@@ -229,8 +245,8 @@ class Sim:
                 assert "lds" in l and self.m0_age >= 2, ("M0 written right in front of its LDS-DMA", l)
                 vo = int(a[0][1:])
                 is_a = "%[rsA]" in a[1] or a[1] == "RSA"
-                base = gen.VOA if is_a else gen.VOB
-                assert base <= vo < base + 8 and (vo < gen.VOB) == is_a
+                base = self.voa if is_a else self.vob
+                assert base <= vo < base + 8 and (vo < self.vob) == is_a
                 h, i = (vo - base) // 4, (vo - base) % 4
                 soff = self.val(a[2].split()[0])
                 st = self.stA if is_a else self.stB
@@ -241,7 +257,7 @@ class Sim:
                 acc, fb, fa = int(m[0][0]), int(m[1][0]), int(m[2][0])
                 parts_a = self.frag(fa, self.a_red)
                 parts_b = self.frag(fb, self.b_red)
-                self.mfma_log.append((acc // 16, parts_a, parts_b))
+                self.mfma_log.append((acc // (4 if self.m16 else 16), parts_a, parts_b))
             else:
                 raise AssertionError(f"unmodelled instruction: {l}")
 
@@ -300,3 +316,91 @@ def test_simulated_stream_is_consistent(a_red, b_red, nk, w, walk):
         assert pa == ("A", T, ks, i) and pb == ("B", T, ks, j), (n, acc, pa, pb)
         seen.add((T, ks, i, j))
     assert len(seen) == 64 * nk
+
+
+# ---- the 16 x 16 x 32 loop (round 6) -----------------------------------------------------------------------------
+def v9_voffset16_red(row0, R, ld, half, p, l):
+    kr = p * 4 + (l >> 4)
+    mc = (l & 15) ^ (4 * (kr & 3)) ^ (2 * ((kr >> 3) & 1))
+    return kr * ld * 2 + (half * 128 + mc * 8) * 2
+
+
+def v9_read_offset16(red, l):
+    if not red:
+        row = l & 15
+        return row * 128 + (((l >> 4) ^ ((row >> 1) & 7)) << 4)
+    g, li = l >> 4, l & 15
+    t, c = li >> 2, li & 3
+    return (8 * g + t) * 256 + ((((4 * t) ^ (2 * (g & 1)) ^ (c >> 1))) << 4) + ((c & 1) << 3)
+
+
+def test_addressing_identities_of_the_16x16x32_loop():
+    """gemm_v9_impl.inc v9_voffset<true, true> / v9_read_offset16 against what the generated asm assumes: a wave's LDS-DMA
+    voffsets = piece 0's + strides (the extra swizzle bit of the reduction-major image is the same for every piece of a
+    wave); a K-major fragment f of k32-step h is read at (address ^ (h << 6)) + 2048 f and holds rows 16 f + (l & 15),
+    16-byte chunk 4 h + (l >> 4); the two transposing reads of a reduction-major fragment f = 2 a + b at
+    (address ^ ((a << 6) | (b << 5))) + 8192 h (+ 1024) hold k-rows 32 h + 8 (l >> 4) + ((l & 15) >> 2) (+ 4) and columns
+    16 f + 4 (l & 3) .. + 3 of the image the LDS-DMA wrote; and the 32 lanes of a half-wave hit 64 different banks."""
+    ld = 4608
+    for w in range(4):
+        for l in range(64):
+            base = v9_voffset16_red(512, 4096, ld, 0, w, l)
+            for h in range(2):
+                for i in range(4):
+                    assert v9_voffset16_red(512, 4096, ld, h, w + 4 * i, l) == base + 16 * i * ld * 2 + 256 * h
+    for h in range(2):
+        for f in range(8):
+            for l in range(64):
+                addr = (v9_read_offset16(False, l) ^ (h << 6)) + 2048 * f
+                row, chunk = addr // 128, (addr % 128) // 16
+                assert row == 16 * f + (l & 15) and chunk ^ ((row >> 1) & 7) == 4 * h + (l >> 4)
+            a, b = f >> 1, f & 1
+            for part in (0, 1024):
+                addrs = []
+                for l in range(64):
+                    g, li = l >> 4, l & 15
+                    addr = (v9_read_offset16(True, l) ^ ((a << 6) | (b << 5))) + 8192 * h + part
+                    kr, chunk, byte = addr // 256, (addr % 256) // 16, addr % 16
+                    # the image: LDS (k-row, chunk) holds global chunk  chunk ^ 4 (kr & 3) ^ 2 ((kr >> 3) & 1)
+                    col = (chunk ^ (4 * (kr & 3)) ^ (2 * ((kr >> 3) & 1))) * 8 + byte // 2
+                    assert kr == 32 * h + 8 * g + (li >> 2) + part // 256 and col == 16 * f + 4 * (li & 3)
+                    addrs.append(addr)
+                for half in range(2):
+                    banks = [((x // 4) + d) % 64 for x in addrs[32 * half:32 * half + 32] for d in range(2)]
+                    assert len(set(banks)) == 64
+
+
+def _lines16(a_red, b_red, walk=False):
+    return [l.replace("@SFX@", "bf16").replace("%=", "X") for l in gen.loop_text16(a_red, b_red, walk)]
+
+
+@pytest.mark.parametrize("a_red,b_red", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("nk", [2, 3, 4, 5, 8, 9])
+@pytest.mark.parametrize("w", [0, 1, 2, 3])
+@pytest.mark.parametrize("walk", [False, True])
+def test_simulated_stream_of_the_16x16x32_loop_is_consistent(a_red, b_red, nk, w, walk):
+    """the same single-wave simulation for the shipped loop: 128 MFMAs per K-tile -- tile T, k32-step h, accumulator (i, j)
+    <- A fragment i x B fragment j of exactly that tile and step, each once -- every fragment read from a half-slot whose
+    LDS-DMA was waited for and published by a barrier, every LDS-DMA into a slot only behind a barrier that follows the
+    last read of its previous content, every piece of every K-tile requested exactly once."""
+    sim = Sim(a_red, b_red, nk, w, m16=True)
+    wr, wc = w >> 1, w & 1
+    sub = {"%[stA]": str(sim.stA), "%[stB]": str(sim.stB), "%[nk]": str(nk), "%[wv]": str(w * 1024),
+           "%[iA]": "1000000", "%[iB]": "2000000", "%[voA]": "0", "%[voB]": "0", "%[adA]": str(wr * HALF),
+           "%[adB]": str(B_BASE + wc * HALF), "%[rsB]": "RSB", "%[rsA]": "RSA"}
+    lines = []
+    for l in _lines16(a_red, b_red, walk):
+        for k, v in sub.items():
+            l = l.replace(k, v)
+        lines.append(l)
+    sim.run(lines)
+    want = {(op, t, h, i) for op in "AB" for t in range(nk) for h in range(2) for i in range(4)}
+    assert set(sim.requested) == want
+    assert len(sim.mfma_log) == 128 * nk
+    seen = set()
+    for n, (acc, pa, pb) in enumerate(sim.mfma_log):
+        T, h = n // 128, (n % 128) // 64
+        i, j = acc // 8, acc % 8
+        assert pa == ("A", T, h, i) and pb == ("B", T, h, j), (n, acc, pa, pb)
+        seen.add((T, h, i, j))
+    assert len(seen) == 128 * nk
