@@ -203,9 +203,37 @@ def test_gemm_v9_hand_placed_k_loop(dev, dtype, a_red, b_red, M, N, K):
     assert torch.equal(outs[15], outs[11])
 
 
+@pytest.mark.parametrize("dtype", H16)
+@pytest.mark.parametrize("M,N,K,alpha", [(4096, 4096, 256, 1.0), (4608, 4096, 704, 0.5), (8192, 4096, 128, 1.0)])
+def test_gemm_v9_register_epilogue_with_residual(dev, dtype, M, N, K, alpha):
+    """round 6: v9's loops run on 16 x 16 x 32 MFMAs and its epilogue is all-in-registers (a lane owns 4 consecutive columns
+    of one row: 8-byte accesses) in two fixed forms -- alpha, and alpha + RESIDUAL (o_proj / down_proj forward: modeling.py
+    :215,:140 + the residual add of :281,:289 folded in).  The residual form against v7's LDS-transposed epilogue: bit for
+    bit, whole rounds (walking) and 288 tiles (tail on v7's sub-tile kernels), C pitch 8- but not 16-byte aligned included."""
+    from macaw_llm_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = _rand((M, K), dtype, g).to(dev)
+    B = _rand((N, K), dtype, g, 0.1).to(dev)
+    for ldc in (N, N + 4):
+        R = _rand((M, ldc), dtype, g).to(dev)
+        outs = {}
+        try:
+            for cfg in (15, 11):
+                lib.mk_gemm_set_cfg(cfg)
+                C = torch.full((M, ldc), float("nan"), dtype=dtype, device=dev)
+                ops.gemm_raw(A, B, C, M, N, K, K, K, ldc, R=R, ldr=ldc, alpha=alpha)
+                outs[cfg] = C
+        finally:
+            lib.mk_gemm_set_cfg(-1)
+        ref = (alpha * (A.float() @ B.float().t()) + R[:, :N].float()).cpu()
+        _close(outs[15][:, :N], ref, dtype, scale=0.1 * math.sqrt(K) + 1.0, what=f"v9 residual epilogue {M}x{N}x{K} ldc {ldc}")
+        assert torch.equal(outs[15][:, :N], outs[11][:, :N])
+
+
 def test_gemm_v9_epilogue_and_fallback(dev):
-    """bias + GELU + residual + accumulate through v9's row-by-row epilogue out of the accumulator file; a ragged
-    problem forced to cfg 15 is computed by v7 (whole tiles only) and stays correct."""
+    """a problem with bias + GELU + residual + accumulate forced to cfg 15 is routed to v7 (round 6: v9's register epilogue
+    has the alpha and alpha + residual forms only), and so is a ragged one (whole tiles only); both stay correct."""
     from macaw_llm_amd import lib as L
     lib = L.load()
     for M, N, K in ((4096, 4096, 256), (4000, 4100, 200)):
