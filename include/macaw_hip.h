@@ -263,6 +263,30 @@ int mk_flash_attn_bwd(const void* q, const void* k, const void* v, const void* o
                       int64_t v_ld, int64_t v_bs, int64_t o_ld, int64_t o_bs, float scale,
                       int32_t causal, int32_t dtype, void* stream);
 
+/* mk_flash_attn_fwd / _bwd with the rotary embedding of q and k (modeling.py:76-91, 167-170) folded in: q and k are
+ * the UNROTATED projections, rotated on their way into the kernel with mk_rope's arithmetic (each product and the
+ * sum rounded to the element type: q, k as the products see them are bit-identical to mk_rope followed by
+ * mk_flash_attn_*); dq and dk come back as gradients of the unrotated tensors (rounded to the element type, then
+ * rotated back -- what mk_rope(inverse) after mk_flash_attn_bwd yields).  cos_t / sin_t [positions][hd] of the
+ * element type, 16-byte aligned; pos[b * Lq + token] int32.  Only where every q / k element enters the kernel once:
+ * hd == 128, Lq == Lk <= 160 (the one-workgroup-per-(b, h) kernels); otherwise MK_ERR_UNSUPPORTED and the caller
+ * runs mk_rope itself.  mk_flash_attn_rope_bwd with qk_rotated = 1: q and k ARE the rotated tensors (mk_rope ran
+ * before mk_flash_attn_fwd) and only the rotation of dq / dk back is folded into the kernel's stores -- the form the
+ * training step uses (one rotation per element instead of three: profiles/r06_rope_fuse.txt). */
+int mk_flash_attn_rope_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                           const int32_t* kmask, const void* cos_t, const void* sin_t,
+                           const int32_t* pos, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
+                           int64_t q_ld, int64_t q_bs, int64_t k_ld, int64_t k_bs, int64_t v_ld,
+                           int64_t v_bs, int64_t o_ld, int64_t o_bs, float scale, int32_t causal,
+                           int32_t dtype, void* stream);
+int mk_flash_attn_rope_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                           const float* lse, float* dvec, void* dq, void* dk, void* dv,
+                           const int32_t* kmask, const void* cos_t, const void* sin_t,
+                           const int32_t* pos, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
+                           int64_t q_ld, int64_t q_bs, int64_t k_ld, int64_t k_bs, int64_t v_ld,
+                           int64_t v_bs, int64_t o_ld, int64_t o_bs, float scale, int32_t causal,
+                           int32_t qk_rotated, int32_t dtype, void* stream);
+
 /* Shifted cross-entropy (modeling.py:600-610). The caller passes labels already shifted
  * (row r predicts labels[r]; -100 = ignore).  row_loss[r] = lse_r - logit[r][label] (0 when
  * ignored), row_lse[r] kept for backward, loss_sum_cnt = {sum of row losses, number of valid

@@ -68,3 +68,33 @@ extern "C" int mk_flash_attn_bwd(const void* q, const void* k, const void* v, co
   if (dtype == MK_F16) return e_f16::flash_attn_bwd_impl(q, k, v, o, dout, lse, dvec, dq, dk, dv, kmask, B, H, Lq, Lk, hd, q_ld, q_bs, k_ld, k_bs, v_ld, v_bs, o_ld, o_bs, scale, causal, dtype, stream);
   return e_bf16::flash_attn_bwd_impl(q, k, v, o, dout, lse, dvec, dq, dk, dv, kmask, B, H, Lq, Lk, hd, q_ld, q_bs, k_ld, k_bs, v_ld, v_bs, o_ld, o_bs, scale, causal, dtype, stream);
 }
+
+// The same two kernels with RoPE (modeling.py:76-91, 167-170) folded in: q and k arrive UNROTATED, are rotated on
+// their way into registers / LDS with mk_rope's arithmetic (bit-identical q, k), dq and dk leave as gradients of the
+// unrotated tensors (mk_flash_attn_rope_bwd with qk_rotated = 1: q and k ARE the rotated tensors -- mk_rope ran before
+// the forward -- and only the rotation of dq / dk back is folded in).  Short sequences only (head_dim 128, Lq == Lk <= 160: the one-workgroup-per-(b, h) kernels, where
+// every q / k element is loaded once); anything else returns MK_ERR_UNSUPPORTED and the caller launches mk_rope.
+extern "C" int mk_flash_attn_rope_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                                      const int32_t* kmask, const void* cos_t, const void* sin_t,
+                                      const int32_t* pos, int32_t B, int32_t H, int32_t Lq, int32_t Lk,
+                                      int32_t hd, int64_t q_ld, int64_t q_bs, int64_t k_ld, int64_t k_bs,
+                                      int64_t v_ld, int64_t v_bs, int64_t o_ld, int64_t o_bs, float scale,
+                                      int32_t causal, int32_t dtype, void* stream) {
+  if (!cos_t || !sin_t || !pos) return MK_ERR_BAD_ARG;
+  if (hd != 128 || Lq != Lk || Lk > 160) return MK_ERR_UNSUPPORTED;
+  if (dtype == MK_F16) return e_f16::flash_attn_fwd_impl(q, k, v, o, lse, kmask, B, H, Lq, Lk, hd, q_ld, q_bs, k_ld, k_bs, v_ld, v_bs, o_ld, o_bs, scale, causal, dtype, stream, cos_t, sin_t, pos);
+  return e_bf16::flash_attn_fwd_impl(q, k, v, o, lse, kmask, B, H, Lq, Lk, hd, q_ld, q_bs, k_ld, k_bs, v_ld, v_bs, o_ld, o_bs, scale, causal, dtype, stream, cos_t, sin_t, pos);
+}
+
+extern "C" int mk_flash_attn_rope_bwd(const void* q, const void* k, const void* v, const void* o,
+                                      const void* dout, const float* lse, float* dvec, void* dq, void* dk,
+                                      void* dv, const int32_t* kmask, const void* cos_t, const void* sin_t,
+                                      const int32_t* pos, int32_t B, int32_t H, int32_t Lq, int32_t Lk,
+                                      int32_t hd, int64_t q_ld, int64_t q_bs, int64_t k_ld, int64_t k_bs,
+                                      int64_t v_ld, int64_t v_bs, int64_t o_ld, int64_t o_bs, float scale,
+                                      int32_t causal, int32_t qk_rotated, int32_t dtype, void* stream) {
+  if (!cos_t || !sin_t || !pos) return MK_ERR_BAD_ARG;
+  if (hd != 128 || Lq != Lk || Lk > 160) return MK_ERR_UNSUPPORTED;
+  if (dtype == MK_F16) return e_f16::flash_attn_bwd_impl(q, k, v, o, dout, lse, dvec, dq, dk, dv, kmask, B, H, Lq, Lk, hd, q_ld, q_bs, k_ld, k_bs, v_ld, v_bs, o_ld, o_bs, scale, causal, dtype, stream, cos_t, sin_t, pos, qk_rotated);
+  return e_bf16::flash_attn_bwd_impl(q, k, v, o, dout, lse, dvec, dq, dk, dv, kmask, B, H, Lq, Lk, hd, q_ld, q_bs, k_ld, k_bs, v_ld, v_bs, o_ld, o_bs, scale, causal, dtype, stream, cos_t, sin_t, pos, qk_rotated);
+}

@@ -160,6 +160,12 @@ class LlamaLayerFn(torch.autograd.Function):
         H, hd = n_heads, D // n_heads
         FF = wg.shape[0]
         _, y1, rstd1 = ops.rmsnorm_fwd(x2, ln1, eps)
+        use_flash = flash_ok(x2.dtype, hd)
+        # short sequences (ops.rope_fuse_mode): "bwd" -- q, k rotated by mk_rope as ever, only the backward kernel folds
+        # the rotation of dq / dk back into its stores; "full" -- q, k stay UNROTATED in HBM, also as the tensors saved
+        # for the backward, and every kernel rotates them on the way in
+        fuse = ops.rope_fuse_mode() if use_flash and ops.flash_rope_ok(hd, S, S, cos, x2) else "off"
+        rope_in = (cos, sin, pos) if fuse == "full" else None
         if wqkv is not None:
             if FP8["qkv"] and _fp8_ok(y1, wqkv):
                 qkv = _fp8_linear(y1, wqkv)                   # e4m3 x e4m3 -> bf16 (cfg 5)
@@ -167,20 +173,21 @@ class LlamaLayerFn(torch.autograd.Function):
                 qkv = ops.linear_fwd(y1, wqkv)                # [M, 3D]
             q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
             ldq = 3 * D
-            ops.rope_(qkv[:, :2 * D], cos, sin, pos, 2 * H, hd)   # q and k heads in one launch
+            if rope_in is None:
+                ops.rope_(qkv[:, :2 * D], cos, sin, pos, 2 * H, hd)   # q and k heads in one launch
         else:
             q, k, v = ops.linear_fwd(y1, wq), ops.linear_fwd(y1, wk), ops.linear_fwd(y1, wv)
             ldq = D
-            ops.rope_(q, cos, sin, pos, H, hd)
-            ops.rope_(k, cos, sin, pos, H, hd)
+            if rope_in is None:
+                ops.rope_(q, cos, sin, pos, H, hd)
+                ops.rope_(k, cos, sin, pos, H, hd)
         att = torch.empty((M, D), dtype=x2.dtype, device=x2.device)
-        use_flash = flash_ok(x2.dtype, hd)
         if use_flash:
             # fused attention: the S x S scores never reach HBM; training keeps only the
             # per-row log-sum-exp and recomputes P in the fused backward
             lse = torch.empty((B, H, S), dtype=torch.float32, device=x2.device) if grad_mode else None
             ops.flash_attn_fwd(q, k, v, att, B, H, S, S, hd, ldq, S * ldq, ldq, S * ldq, ldq, S * ldq,
-                               D, S * D, 1.0 / math.sqrt(hd), kmask=kmask, causal=True, lse=lse)
+                               D, S * D, 1.0 / math.sqrt(hd), kmask=kmask, causal=True, lse=lse, rope=rope_in)
             probs = lse
         else:
             probs, _ = attention_fwd(TDesc(q, ldq, S * ldq), TDesc(k, ldq, S * ldq),
@@ -201,7 +208,10 @@ class LlamaLayerFn(torch.autograd.Function):
             out = _fp8_linear(a, wd, residual=h1)
         else:
             out = ops.linear_fwd(a, wd, residual=h1)
-        return out, (rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, gu, a), use_flash
+        # (the third value tells the backward what its fused kernel has to do: 1 = nothing, 2 = q, k unrotated, RoPE
+        # inside the kernels; 3 = q, k rotated, dq / dk rotated back at the store)
+        return out, (rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, gu, a), \
+            ({"full": 2, "bwd": 3, "off": 1}[fuse] if use_flash else 0)
 
     @staticmethod
     def forward(ctx, x, kmask, pos, cos, sin, n_heads, eps, wq, wk, wv, wo, wg, wu, wd, ln1, ln2,
@@ -233,7 +243,7 @@ class LlamaLayerFn(torch.autograd.Function):
         B, S, D, H, hd, use_flash, FF = ctx.dims
         M = B * S
         if ctx.recompute:
-            _, (rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, gu, a), _ = LlamaLayerFn._fwd(
+            _, (rstd1, y1, q, k, v, probs, att, h1, rstd2, y2, g, u, gu, a), use_flash = LlamaLayerFn._fwd(
                 x2, B, S, kmask, pos, cos, sin, ctx.n_heads, ctx.eps, wq, wk, wv, wo, wg, wu, wd, ln1,
                 ln2, wqkv, wgu, True)
         need = ctx.needs_input_grad
@@ -270,15 +280,18 @@ class LlamaLayerFn(torch.autograd.Function):
         else:
             dqkv = None
             dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        rope_in = (cos, sin, pos) if use_flash >= 2 else None
         if use_flash:
             ops.flash_attn_bwd(q, k, v, att, datt, probs, dq, dk, dv, B, H, S, S, hd, ldq, S * ldq,
                                ldq, S * ldq, ldq, S * ldq, D, S * D, 1.0 / math.sqrt(hd),
-                               kmask=kmask, causal=True)
+                               kmask=kmask, causal=True, rope=rope_in, qk_rotated=use_flash == 3)
         else:
             d = lambda t: TDesc(t, ldq, S * ldq)  # noqa: E731
             attention_bwd(TDesc(datt, D, S * D), d(q), d(k), d(v), probs, None, d(dq), d(dk), d(dv),
                           B, H, S, S, hd, 1.0 / math.sqrt(hd))
-        if dqkv is not None:
+        if rope_in is not None:
+            pass                                               # dq, dk already are gradients of the unrotated q, k
+        elif dqkv is not None:
             ops.rope_(dqkv[:, :2 * D], cos, sin, pos, 2 * H, hd, inverse=True)
         else:
             ops.rope_(dq, cos, sin, pos, H, hd, inverse=True)

@@ -93,6 +93,8 @@ SIGNATURES = {
     "mk_flash_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64,
                           _i64, _i64, _i64, _i64, _i64, _f32, _i32, _i32, _vp],
     "mk_flash_attn_bwd": [_vp] * 11 + [_i32] * 5 + [_i64] * 8 + [_f32, _i32, _i32, _vp],
+    "mk_flash_attn_rope_fwd": [_vp] * 9 + [_i32] * 5 + [_i64] * 8 + [_f32, _i32, _i32, _vp],
+    "mk_flash_attn_rope_bwd": [_vp] * 14 + [_i32] * 5 + [_i64] * 8 + [_f32, _i32, _i32, _i32, _vp],
     "mk_cross_entropy": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp],
     "mk_cross_entropy_bwd": [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i64, _i32, _vp],
     "mk_argmax_rows": [_vp, _i64, _i32, _i32, _vp, _i32, _vp],

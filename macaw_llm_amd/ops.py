@@ -8,6 +8,7 @@ there is no eager / CPU fallback on the product path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -659,11 +660,43 @@ def softmax_bwd_(probs, dprobs, nz, Lq, Lk, ld, scale=1.0, dropout_p=0.0, seed=0
     return dprobs
 
 
+def flash_rope_ok(hd, Lq, Lk, cos_t, x) -> bool:
+    """RoPE can ride inside the fused attention kernels (mk_flash_attn_rope_*): the one-workgroup-per-(b, h)
+    short-sequence kernels, tables in the activations' dtype."""
+    return (hd == 128 and Lq == Lk and Lk <= 160 and cos_t.dtype == x.dtype and cos_t.shape[-1] == hd
+            and cos_t.is_contiguous())
+
+
+def rope_fuse_mode() -> str:
+    """how LlamaLayerFn folds RoPE into the short-sequence attention kernels (MACAW_ROPE_FUSE, read per layer call).
+    "off" (default): mk_rope before the forward, mk_rope(inverse) behind the backward -- three launches;
+    "bwd": the rotation of dq / dk back inside the backward kernel's stores; "full": q, k stay unrotated in HBM and
+    are rotated on every load (three rotations per element in the backward).  All three are bit-identical
+    (tests/test_kernels_gpu.py); measured in the cfg-3 step the fused forms save the 1.9 ms of the two in-place
+    launches and spend 0.9 (bwd) / 1.8 ms (full) more inside the attention kernels, whose tails wait for the table
+    rows and round six times per output pair: 215.1-215.6 / 214.6-215.2 / 215.0-215.5 ms -- no gain, so the plain
+    form stays the default (profiles/r06_rope_fuse.txt)."""
+    m = os.environ.get("MACAW_ROPE_FUSE", "off")
+    if m not in ("bwd", "full", "off"):
+        raise MacawHipError(f"MACAW_ROPE_FUSE={m!r}: expected bwd, full or off")
+    return m
+
+
 def flash_attn_fwd(q, k, v, o, B, H, Lq, Lk, hd, q_ld, q_bs, k_ld, k_bs, v_ld, v_bs, o_ld, o_bs,
-                   scale, kmask=None, causal=False, lse=None, q_off=0, k_off=0, v_off=0, o_off=0):
-    """fused attention forward on strided bf16 buffers (element offsets/strides)"""
+                   scale, kmask=None, causal=False, lse=None, q_off=0, k_off=0, v_off=0, o_off=0,
+                   rope=None):
+    """fused attention forward on strided bf16 buffers (element offsets/strides).
+    rope = (cos_t, sin_t, pos): q and k are the unrotated projections (see flash_rope_ok)"""
     lib = _L.load()
     es = q.element_size()
+    if rope is not None:
+        cos_t, sin_t, pos = rope
+        _L.check(lib.mk_flash_attn_rope_fwd(_p(q) + q_off * es, _p(k) + k_off * es, _p(v) + v_off * es,
+                                            _p(o) + o_off * es, _p(lse), _p(kmask), _p(cos_t), _p(sin_t),
+                                            _p(pos), B, H, Lq, Lk, hd, q_ld, q_bs, k_ld, k_bs, v_ld, v_bs,
+                                            o_ld, o_bs, float(scale), int(causal), dt(q), _st()),
+                 "mk_flash_attn_rope_fwd")
+        return o
     _L.check(lib.mk_flash_attn_fwd(_p(q) + q_off * es, _p(k) + k_off * es, _p(v) + v_off * es,
                                    _p(o) + o_off * es, _p(lse), _p(kmask), B, H, Lq, Lk, hd, q_ld,
                                    q_bs, k_ld, k_bs, v_ld, v_bs, o_ld, o_bs, float(scale),
@@ -672,9 +705,19 @@ def flash_attn_fwd(q, k, v, o, B, H, Lq, Lk, hd, q_ld, q_bs, k_ld, k_bs, v_ld, v
 
 
 def flash_attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, B, H, Lq, Lk, hd, q_ld, q_bs, k_ld, k_bs, v_ld,
-                   v_bs, o_ld, o_bs, scale, kmask=None, causal=False):
+                   v_bs, o_ld, o_bs, scale, kmask=None, causal=False, rope=None, qk_rotated=False):
+    """rope = (cos_t, sin_t, pos): dq / dk come back as gradients of the UNROTATED q, k; q and k themselves are
+    the unrotated tensors, or with qk_rotated the rotated ones (mk_rope ran before the forward)"""
     lib = _L.load()
     dvec = torch.empty(B * H * Lq, dtype=torch.float32, device=q.device)
+    if rope is not None:
+        cos_t, sin_t, pos = rope
+        _L.check(lib.mk_flash_attn_rope_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(dvec), _p(dq),
+                                            _p(dk), _p(dv), _p(kmask), _p(cos_t), _p(sin_t), _p(pos), B, H,
+                                            Lq, Lk, hd, q_ld, q_bs, k_ld, k_bs, v_ld, v_bs, o_ld, o_bs,
+                                            float(scale), int(causal), int(qk_rotated), dt(q), _st()),
+                 "mk_flash_attn_rope_bwd")
+        return
     _L.check(lib.mk_flash_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(dvec), _p(dq),
                                    _p(dk), _p(dv), _p(kmask), B, H, Lq, Lk, hd, q_ld, q_bs, k_ld,
                                    k_bs, v_ld, v_bs, o_ld, o_bs, float(scale), int(causal), dt(q),

@@ -965,6 +965,108 @@ def test_flash_attention_bwd_short_sequences(dev, dtype, S, causal, masked):
     assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
 
 
+@pytest.mark.parametrize("S,causal,masked,fused_qkv", [(144, True, True, True), (160, True, False, False), (160, False, True, True),
+                                                       (129, True, False, True), (96, True, True, False), (33, True, True, True),
+                                                       (5, True, False, True), (1, True, False, False), (150, False, False, True)])
+@pytest.mark.parametrize("dtype", H16)
+def test_flash_attention_with_rope_inside_is_bit_identical_to_the_three_launches(dev, dtype, S, causal, masked, fused_qkv):
+    """mk_flash_attn_rope_fwd / _bwd (RoPE applied to q and k on their way into the short-sequence kernels, dq / dk rotated
+    back at the store) against mk_rope -> mk_flash_attn_fwd / _bwd -> mk_rope(inverse): o, lse, dq, dk, dv BIT-IDENTICAL
+    (same rounding points: modeling.py:76-91 in the element type).  Positions are NOT arange (shifted per sample, as
+    a left-padded batch has them), q | k | v both as three tensors and as column blocks of one [M, 3D] buffer, untouched
+    input buffers, 3 x 3 (b, h) so that every wave rotation occurs."""
+    g = torch.Generator().manual_seed(S * 17 + causal + 2 * masked)
+    Bn, H, hd = 3, 3, 128
+    D = H * hd
+    cos, sin = restate.rotary_tables(hd, 256)
+    cos, sin = cos.to(dtype).to(dev).contiguous(), sin.to(dtype).to(dev).contiguous()
+    pos = (torch.arange(S)[None, :] + torch.tensor([0, 7, 91])[:, None]).reshape(-1).to(torch.int32).to(dev)
+    if fused_qkv:
+        qkv = _rand((Bn * S, 3 * D), dtype, g, 0.7).to(dev)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        ld = 3 * D
+    else:
+        q, k, v = (_rand((Bn * S, D), dtype, g, 0.7).to(dev) for _ in range(3))
+        ld = D
+    do = _rand((Bn * S, D), dtype, g).to(dev)
+    kmask = torch.ones(Bn, S, dtype=torch.int32)
+    if masked:
+        kmask[1, -min(11, S - 1):] = 0
+    km_d = kmask.to(dev) if masked else None
+    scale = hd ** -0.5
+    geo = (ld, S * ld, ld, S * ld, ld, S * ld, D, S * D)
+    assert ops.flash_rope_ok(hd, S, S, cos, q)
+    # ---- three launches
+    if fused_qkv:
+        rot = qkv.clone()
+        ops.rope_(rot[:, :2 * D], cos, sin, pos, 2 * H, hd)
+        qr, kr, vr = rot[:, :D], rot[:, D:2 * D], rot[:, 2 * D:]
+    else:
+        qr, kr, vr = q.clone(), k.clone(), v
+        ops.rope_(qr, cos, sin, pos, H, hd)
+        ops.rope_(kr, cos, sin, pos, H, hd)
+    o_ref = torch.zeros((Bn * S, D), dtype=dtype, device=dev)
+    lse_ref = torch.empty((Bn, H, S), dtype=torch.float32, device=dev)
+    ops.flash_attn_fwd(qr, kr, vr, o_ref, Bn, H, S, S, hd, *geo, scale, kmask=km_d, causal=causal, lse=lse_ref)
+    nan = float("nan")
+    if fused_qkv:
+        dref = torch.full((Bn * S, 3 * D), nan, dtype=dtype, device=dev)
+        dq_r, dk_r, dv_r = dref[:, :D], dref[:, D:2 * D], dref[:, 2 * D:]
+    else:
+        dq_r, dk_r, dv_r = (torch.full((Bn * S, D), nan, dtype=dtype, device=dev) for _ in range(3))
+    ops.flash_attn_bwd(qr, kr, vr, o_ref, do, lse_ref, dq_r, dk_r, dv_r, Bn, H, S, S, hd, *geo, scale, kmask=km_d, causal=causal)
+    if fused_qkv:
+        ops.rope_(dref[:, :2 * D], cos, sin, pos, 2 * H, hd, inverse=True)
+    else:
+        ops.rope_(dq_r, cos, sin, pos, H, hd, inverse=True)
+        ops.rope_(dk_r, cos, sin, pos, H, hd, inverse=True)
+    # ---- one launch per pass
+    q0, k0 = q.clone(), k.clone()
+    o = torch.zeros((Bn * S, D), dtype=dtype, device=dev)
+    lse = torch.empty((Bn, H, S), dtype=torch.float32, device=dev)
+    ops.flash_attn_fwd(q, k, v, o, Bn, H, S, S, hd, *geo, scale, kmask=km_d, causal=causal, lse=lse, rope=(cos, sin, pos))
+    assert torch.equal(o, o_ref), (o.float() - o_ref.float()).abs().max().item()
+    assert torch.equal(lse, lse_ref)
+    if fused_qkv:
+        dgot = torch.full((Bn * S, 3 * D), nan, dtype=dtype, device=dev)
+        dq, dk, dv = dgot[:, :D], dgot[:, D:2 * D], dgot[:, 2 * D:]
+    else:
+        dq, dk, dv = (torch.full((Bn * S, D), nan, dtype=dtype, device=dev) for _ in range(3))
+    ops.flash_attn_bwd(q, k, v, o, do, lse, dq, dk, dv, Bn, H, S, S, hd, *geo, scale, kmask=km_d, causal=causal,
+                       rope=(cos, sin, pos))
+    assert torch.equal(q, q0) and torch.equal(k, k0), "the fused kernels must leave q and k unrotated in HBM"
+    for name, got, ref in (("dq", dq, dq_r), ("dk", dk, dk_r), ("dv", dv, dv_r)):
+        assert torch.isfinite(got).all(), name
+        assert torch.equal(got, ref), (name, (got.float() - ref.float()).abs().max().item())
+    # ---- the training step's form: q, k rotated by mk_rope, only dq / dk rotated back inside the kernel
+    if fused_qkv:
+        dgot2 = torch.full((Bn * S, 3 * D), nan, dtype=dtype, device=dev)
+        dq2, dk2, dv2 = dgot2[:, :D], dgot2[:, D:2 * D], dgot2[:, 2 * D:]
+    else:
+        dq2, dk2, dv2 = (torch.full((Bn * S, D), nan, dtype=dtype, device=dev) for _ in range(3))
+    ops.flash_attn_bwd(qr, kr, vr, o_ref, do, lse_ref, dq2, dk2, dv2, Bn, H, S, S, hd, *geo, scale, kmask=km_d,
+                       causal=causal, rope=(cos, sin, pos), qk_rotated=True)
+    for name, got, ref in (("dq", dq2, dq_r), ("dk", dk2, dk_r), ("dv", dv2, dv_r)):
+        assert torch.equal(got, ref), (name + " (q, k rotated)", (got.float() - ref.float()).abs().max().item())
+
+
+def test_flash_attention_rope_entry_points_refuse_what_the_short_kernels_do_not_cover(dev):
+    """outside hd == 128, Lq == Lk <= 160 the rope entry points return MK_ERR_UNSUPPORTED (the caller then launches
+    mk_rope itself: engine.LlamaLayerFn does, ops.flash_rope_ok is its gate) -- never a silently unrotated result"""
+    dtype = torch.bfloat16
+    Bn, H, hd, S = 1, 2, 128, 192
+    D = H * hd
+    cos, sin = restate.rotary_tables(hd, 256)
+    cos, sin = cos.to(dtype).to(dev).contiguous(), sin.to(dtype).to(dev).contiguous()
+    pos = torch.arange(S, dtype=torch.int32, device=dev)
+    q = torch.zeros((S, D), dtype=dtype, device=dev)
+    o = torch.zeros_like(q)
+    assert not ops.flash_rope_ok(hd, S, S, cos, q)
+    with pytest.raises(ops.MacawHipError):
+        ops.flash_attn_fwd(q, q, q, o, Bn, H, S, S, hd, D, S * D, D, S * D, D, S * D, D, S * D, 1.0, causal=True,
+                           rope=(cos, sin, pos))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cfg", [19, 22])
 @pytest.mark.parametrize("M,N,K", [(32, 4096, 4096), (17, 1000, 1024), (24, 12288, 4096), (32, 250, 192),
