@@ -451,6 +451,8 @@ def main():
             # that no kernel of another stream runs beside the GEMMs and a launch's duration is its own (the other
             # steps overlap the per-bucket AdamW launches with the backward on one rank: BucketedStep.local_overlap)
             runtime.serial_update = True
+            from macaw_llm_amd import engine as _engine
+            _engine.DW_SIDE["on"] = False        # (grad-weight GEMMs back on the compute stream for this step, see engine.DW_SIDE)
             ops.prof_begin()
             runtime.profile_comm(True)
         loss = step(eager=last)

@@ -96,6 +96,55 @@ def attention_bwd(do: TDesc, q: TDesc, k: TDesc, v: TDesc, probs, pd, dq: TDesc,
 # "mlp" extends the same treatment to gate|up and down (beyond BASELINE cfg 5's wording; off unless asked).
 FP8 = {"qkv": False, "align": False, "mlp": False}
 
+# Grad-weight GEMMs of a decoder layer on a SECOND stream beside the grad-input GEMMs of the first.  dx = dy W and
+# dW = dy^T x of a projection are independent, and a grad-input GEMM with fewer 256 x 256 tiles than the chip has CUs
+# (M = 2176 at BASELINE cfg 2: 9 x 16 = 144 tiles on 256 CUs, one round at 56 % occupancy) leaves CUs idle that the
+# grad-weight GEMM's workgroups can take.  The grad-input launch is submitted FIRST (it gets its CUs), the grad-weight
+# launch waits only for the event recorded when dy was complete; the layer's backward joins the side stream before it
+# returns, so gradient hooks, bucket collectives and the optimizer see finished gradients exactly as before.  Same
+# kernels on the same operands (the GEMM scratch is per stream, ops._workspace): results are bit-identical.
+# Measured (profiles/r06_dw_side_stream.txt): cfg 2 136.0 / 135.4 -> 131.0 / 130.1 ms per step (+3.9 %), cfg 3 (M = 4608:
+# 288 tiles, whose 32-tile tail already fills the chip as eighths) +-0 -- so "auto" (default) turns it on only where the
+# [M, D] grad-input GEMMs are less than one round.  MACAW_DW_STREAM = 0 | 1 | auto; DW_SIDE["on"] at run time
+# (bench.py switches it off for its instrumented last step: per-launch durations need serial launches).
+DW_SIDE = {"on": {"0": False, "1": True}.get(__import__("os").environ.get("MACAW_DW_STREAM", "auto"), "auto"), "streams": {}}
+
+
+class _DwSide:
+    """fork / launch / join of one layer's grad-weight GEMMs (no-op object when off)"""
+
+    def __init__(self, dev, M=0, D=0):
+        self.side = None
+        on = DW_SIDE["on"]
+        if on == "auto":
+            on = (dev.type == "cuda" and M >= 256 and
+                  ((M + 255) // 256) * ((D + 255) // 256) < torch.cuda.get_device_properties(dev).multi_processor_count)
+        # (inside a hipGraph capture every stream shares the device's ONE GEMM scratch: stay on the capture stream)
+        if on and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            st = DW_SIDE["streams"].get(dev)
+            if st is None:
+                st = DW_SIDE["streams"][dev] = torch.cuda.Stream(device=dev)
+            self.side, self.main, self.used = st, torch.cuda.current_stream(dev), False
+
+    def fork(self):
+        """call when dy is complete on the main stream, BEFORE the grad-input launch"""
+        return self.main.record_event() if self.side is not None else None
+
+    def dw(self, ev, dy, x, w):
+        if self.side is None:
+            return ops.linear_dw(dy, x, w=w)
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            out = ops.linear_dw(dy, x, w=w)
+        for t in (dy, x, out):
+            t.record_stream(self.side)       # (the allocator must not hand these blocks out before the side GEMM ran)
+        self.used = True
+        return out
+
+    def join(self):
+        if self.side is not None and self.used:
+            self.main.wait_stream(self.side)
+
 
 def _fp8_ok(x, W) -> bool:
     """x [M, K] bf16 rows, W [N, K]: fp8 needs K % 128 (MFMA k-slots) and 16-byte aligned pitches"""
@@ -248,17 +297,20 @@ class LlamaLayerFn(torch.autograd.Function):
                 ln2, wqkv, wgu, True)
         need = ctx.needs_input_grad
         dout2 = _c2(dout, M, D)
+        sd = _DwSide(x2.device, M, D)
         # ---- MLP
         fp8_mlp = FP8["mlp"] and gu is not None and _fp8_dx_ok(dout2, wd) and _fp8_ok(y2, wgu)
+        ev = sd.fork()
         da = _fp8_dx(dout2, wd) if fp8_mlp else ops.linear_dx(dout2, wd)
-        dwd = ops.linear_dw(dout2, a, w=wd) if need[13] else None
+        dwd = sd.dw(ev, dout2, a, wd) if need[13] else None
         dwg = dwu = None
         if gu is not None:
             dgu = ops.swiglu2d_bwd(gu, da, FF)
             del da
+            ev = sd.fork()
             dy2 = _fp8_dx(dgu, wgu) if (fp8_mlp and _fp8_dx_ok(dgu, wgu)) else ops.linear_dx(dgu, wgu)
             if need[11] or need[12]:
-                dwgu = ops.linear_dw(dgu, y2, w=wgu)           # [2FF, D]
+                dwgu = sd.dw(ev, dgu, y2, wgu)                 # [2FF, D]
                 dwg, dwu = dwgu[:FF], dwgu[FF:]
             del dgu
         else:
@@ -271,8 +323,9 @@ class LlamaLayerFn(torch.autograd.Function):
             del dg, du
         dh1, dln2 = ops.rmsnorm_bwd(dy2, h1, ln2, rstd2, dres=dout2, dw_out=ops.grad_dst(ln2) if need[15] else None)
         # ---- attention
+        ev = sd.fork()
         datt = ops.linear_dx(dh1, wo)
-        dwo = ops.linear_dw(dh1, att, w=wo) if need[10] else None
+        dwo = sd.dw(ev, dh1, att, wo) if need[10] else None
         ldq = q.stride(0)
         if wqkv is not None:
             dqkv = torch.empty((M, 3 * D), dtype=q.dtype, device=q.device)
@@ -298,12 +351,13 @@ class LlamaLayerFn(torch.autograd.Function):
             ops.rope_(dk, cos, sin, pos, H, hd, inverse=True)
         dwq = dwk = dwv = None
         if wqkv is not None:
+            ev = sd.fork()
             if FP8["qkv"] and _fp8_dx_ok(dqkv, wqkv) and _fp8_ok(y1, wqkv):
                 dy1 = _fp8_dx(dqkv, wqkv)                      # e4m3 dy x e4m3 W^T (cfg 5)
             else:
                 dy1 = ops.linear_dx(dqkv, wqkv)
             if need[7] or need[8] or need[9]:
-                dwqkv = ops.linear_dw(dqkv, y1, w=wqkv)        # [3D, D]
+                dwqkv = sd.dw(ev, dqkv, y1, wqkv)              # [3D, D]
                 dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]
         else:
             dy1 = ops.linear_dx(dq, wq)
@@ -313,6 +367,7 @@ class LlamaLayerFn(torch.autograd.Function):
             dwk = ops.linear_dw(dk, y1) if need[8] else None
             dwv = ops.linear_dw(dv, y1) if need[9] else None
         dx, dln1 = ops.rmsnorm_bwd(dy1, x2, ln1, rstd1, dres=dh1, dw_out=ops.grad_dst(ln1) if need[14] else None)
+        sd.join()
         return (dx.view(B, S, D), None, None, None, None, None, None, dwq, dwk, dwv, dwo, dwg, dwu,
                 dwd, dln1 if need[14] else None, dln2 if need[15] else None, None, None, None)
 

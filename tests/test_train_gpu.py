@@ -631,3 +631,38 @@ def test_one_rank_updates_overlap_the_backward_and_change_no_bit(dev):
         assert torch.equal(p_ovl[n], p_ser[n]), n
     assert sorted(map(str, rt_ovl.opt.state)) == sorted(map(str, rt_ser.opt.state))
     assert "side stream" in rt_ovl.describe() and "one fused AdamW launch" in rt_ser.describe()
+
+
+def test_grad_weight_gemms_on_the_side_stream_change_no_bit(dev):
+    """engine.DW_SIDE: the grad-weight GEMM of every decoder-layer projection goes out on a second stream beside the
+    grad-input GEMM (submitted first) and the layer's backward joins before it returns ("auto": where the [M, D] grad-input
+    GEMMs fill less than one round of CUs, BASELINE cfg 2).  Same kernels on the same operands, per-stream GEMM scratch,
+    gradients stored straight into the buckets by the side stream: losses, weights and optimizer state bit-identical to
+    the one-stream step, with and without the per-bucket updates behind the backward."""
+    from macaw_llm_amd import engine
+    fx = load_case("micro_all")
+    cfg = configs.get(fx["config_name"])
+    old = engine.DW_SIDE["on"]
+    try:
+        engine.DW_SIDE["on"] = False
+        l_ref, p_ref, _ = _run_bucketed(dev, fx, cfg, 4)
+        engine.DW_SIDE["on"] = True
+        engine.DW_SIDE["streams"].clear()
+        l_side, p_side, _ = _run_bucketed(dev, fx, cfg, 4)
+        assert engine.DW_SIDE["streams"], "the side stream was never created: no grad-weight GEMM went through it"
+        l_both, p_both, _ = _run_bucketed(dev, fx, cfg, 4, local_overlap=True)
+    finally:
+        engine.DW_SIDE["on"] = old
+    assert l_side == l_ref and l_both == l_ref
+    for n in p_ref:
+        assert torch.equal(p_side[n], p_ref[n]), n
+        assert torch.equal(p_both[n], p_ref[n]), n
+    # "auto": on exactly where the grad-input GEMMs of the layer are less than one round of 256 x 256 tiles
+    engine.DW_SIDE["on"] = "auto"
+    try:
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        assert engine._DwSide(dev, 2176, 4096).side is not None          # cfg 2: 9 x 16 = 144 tiles
+        assert engine._DwSide(dev, 4608, 4096).side is None or cus > 288   # cfg 3: 288 tiles
+        assert engine._DwSide(dev, 144, 4096).side is None                # one sample: skinny kernels, left alone
+    finally:
+        engine.DW_SIDE["on"] = old
