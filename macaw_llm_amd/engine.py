@@ -110,6 +110,21 @@ FP8 = {"qkv": False, "align": False, "mlp": False}
 DW_SIDE = {"on": {"0": False, "1": True}.get(__import__("os").environ.get("MACAW_DW_STREAM", "auto"), "auto"), "streams": {}}
 
 
+ENC_SIDE = {"on": bool(__import__("os").environ.get("MACAW_ENC_STREAMS")), "streams": {}}
+
+
+def tower_side_stream(x, tower, other=True):
+    """the stream a FROZEN modality tower may run on beside the other towers, or None (experiment: ENC_SIDE)"""
+    if not (ENC_SIDE["on"] and other and x.is_cuda) or torch.cuda.is_current_stream_capturing():
+        return None
+    if torch.is_grad_enabled() and any(p.requires_grad for p in tower.parameters()):
+        return None
+    st = ENC_SIDE["streams"].get(x.device)
+    if st is None:
+        st = ENC_SIDE["streams"][x.device] = torch.cuda.Stream(device=x.device)
+    return st
+
+
 class _DwSide:
     """fork / launch / join of one layer's grad-weight GEMMs (no-op object when off)"""
 
@@ -510,9 +525,12 @@ class LMHeadLossFn(torch.autograd.Function):
         dlv = dl[:, :V]
         # the pad columns [V, ldv) of dl are zero (ce_bwd writes the whole pitch, `ext` is
         # zero-filled): the K = V reduction of dx runs on the tile kernels over the padded width
+        sd = _DwSide(h2.device, M, D)                    # (see DW_SIDE: the [M, D] grad-input GEMM beside the grad-weight GEMM)
+        ev = sd.fork()
         dy = ops.linear_dx(dlv, lm_w, dy_pad_zero=True)
-        dlm = ops.linear_dw(dlv, y, w=lm_w) if need[2] else None
+        dlm = sd.dw(ev, dlv, y, lm_w) if need[2] else None
         dh, dnw = ops.rmsnorm_bwd(dy, h2, norm_w, rstd, dw_out=ops.grad_dst(norm_w) if need[1] else None)
+        sd.join()
         return dh.view(B, S, D), (dnw if need[1] else None), dlm, None, None
 
 

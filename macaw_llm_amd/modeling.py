@@ -760,9 +760,25 @@ class MM_LLMs(PreTrainedModel):
     def prepare_inputs_for_generation(self, inputs):
         """modeling.py:965-1048 — same outputs (inputs_embeds, attention_mask, labels)."""
         cfg = self.config
+        audio_f, audio_side = None, None
+        if inputs.get("audios") is not None:
+            # The towers are independent of each other: with frozen encoders (run_clm_llms.py:390-393) the audio tower
+            # goes out on a second stream beside the image / video tower (experiment, MACAW_ENC_STREAMS=1; their
+            # short-K GEMMs and 4-wave attention leave CUs idle between rounds)
+            audio_side = eng.tower_side_stream(inputs["audios"], self.audio_encoder,
+                                               other=inputs.get("images") is not None or inputs.get("videos") is not None)
+            if audio_side is not None:
+                audio_side.wait_stream(torch.cuda.current_stream(inputs["audios"].device))
+                with torch.cuda.stream(audio_side):
+                    audio_f = self.encode_audio(inputs["audios"])
+            else:
+                audio_f = self.encode_audio(inputs["audios"])
         image_f = self.encode_image(inputs["images"]) if inputs.get("images") is not None else None
-        audio_f = self.encode_audio(inputs["audios"]) if inputs.get("audios") is not None else None
         video_f = self.encode_video_long(inputs["videos"]) if inputs.get("videos") is not None else None
+        if audio_side is not None:
+            main = torch.cuda.current_stream(audio_f.device)
+            main.wait_stream(audio_side)
+            audio_f.record_stream(main)
         E = self.llm.model.embed_tokens.weight
         ids = inputs["input_ids"]
         _dev_check(ids)
