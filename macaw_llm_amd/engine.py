@@ -160,8 +160,9 @@ class _DwSide:
         self.side.wait_event(ev)
         with torch.cuda.stream(self.side):
             out = ops.linear_dw(dy, x, w=w)
-        for t in (dy, x, out):
+        for t in (dy, x):
             t.record_stream(self.side)       # (the allocator must not hand these blocks out before the side GEMM ran)
+        out.record_stream(self.main)         # (a fresh `out` comes from the side stream's pool and is read on the main one)
         self.used = True
         return out
 
