@@ -666,3 +666,20 @@ def test_grad_weight_gemms_on_the_side_stream_change_no_bit(dev):
         assert engine._DwSide(dev, 144, 4096).side is None                # one sample: skinny kernels, left alone
     finally:
         engine.DW_SIDE["on"] = old
+
+
+def test_bucketed_two_ranks_with_the_grad_weight_side_stream(dev, monkeypatch):
+    """the world-2 ZeRO-1 step (reduce-scatter / shard AdamW / all-gather launched from the gradient hooks) with every
+    decoder layer's grad-weight GEMMs on the side stream (MACAW_DW_STREAM=1 in the ranks): the layer's backward joins
+    before the hooks fire, so the collectives see finished gradients -- replicas identical and identical to the
+    one-stream run, bit for bit."""
+    _require_gloo_on_cuda()
+    plain = _run_bucketed_two_ranks()
+    monkeypatch.setenv("MACAW_DW_STREAM", "1")
+    side = _run_bucketed_two_ranks()
+    assert side[0][1] is True and len(side[0][2]) > 20
+    assert side[0][2] == side[1][2], [n for n in side[0][2] if side[0][2][n] != side[1][2][n]]
+    assert side[0][2] == plain[0][2], [n for n in side[0][2] if side[0][2][n] != plain[0][2][n]]
+    for s_p, s_s in zip(plain[0][3], side[0][3]):
+        for e_p, e_s in zip(s_p, s_s):
+            assert e_p["local_grad"] == e_s["local_grad"] and e_p["updated"] == e_s["updated"], (e_p, e_s)
