@@ -107,7 +107,9 @@ FP8 = {"qkv": False, "align": False, "mlp": False}
 # 288 tiles, whose 32-tile tail already fills the chip as eighths) +-0 -- so "auto" (default) turns it on only where the
 # [M, D] grad-input GEMMs are less than one round.  MACAW_DW_STREAM = 0 | 1 | auto; DW_SIDE["on"] at run time
 # (bench.py switches it off for its instrumented last step: per-launch durations need serial launches).
-DW_SIDE = {"on": {"0": False, "1": True}.get(__import__("os").environ.get("MACAW_DW_STREAM", "auto"), "auto"), "streams": {}}
+DW_SIDE = {"on": {"0": False, "1": True}.get(__import__("os").environ.get("MACAW_DW_STREAM", "auto"), "auto"), "streams": {},
+           # which projections' pairs go out on two streams when it is on (A/B switch: MACAW_DW_PAIRS=o,qkv ...)
+           "pairs": set((__import__("os").environ.get("MACAW_DW_PAIRS") or "down,gu,o,qkv,lm").split(","))}
 
 
 # Frozen audio tower on a second stream beside the image / video tower (experiment, MACAW_ENC_STREAMS=1; off by default):
@@ -154,8 +156,8 @@ class _DwSide:
         """call when dy is complete on the main stream, BEFORE the grad-input launch"""
         return self.main.record_event() if self.side is not None else None
 
-    def dw(self, ev, dy, x, w):
-        if self.side is None:
+    def dw(self, ev, dy, x, w, pair=None):
+        if self.side is None or (pair is not None and pair not in DW_SIDE["pairs"]):
             return ops.linear_dw(dy, x, w=w)
         self.side.wait_event(ev)
         with torch.cuda.stream(self.side):
@@ -327,7 +329,7 @@ class LlamaLayerFn(torch.autograd.Function):
         fp8_mlp = FP8["mlp"] and gu is not None and _fp8_dx_ok(dout2, wd) and _fp8_ok(y2, wgu)
         ev = sd.fork()
         da = _fp8_dx(dout2, wd) if fp8_mlp else ops.linear_dx(dout2, wd)
-        dwd = sd.dw(ev, dout2, a, wd) if need[13] else None
+        dwd = sd.dw(ev, dout2, a, wd, "down") if need[13] else None
         dwg = dwu = None
         if gu is not None:
             dgu = ops.swiglu2d_bwd(gu, da, FF)
@@ -335,7 +337,7 @@ class LlamaLayerFn(torch.autograd.Function):
             ev = sd.fork()
             dy2 = _fp8_dx(dgu, wgu) if (fp8_mlp and _fp8_dx_ok(dgu, wgu)) else ops.linear_dx(dgu, wgu)
             if need[11] or need[12]:
-                dwgu = sd.dw(ev, dgu, y2, wgu)                 # [2FF, D]
+                dwgu = sd.dw(ev, dgu, y2, wgu, "gu")             # [2FF, D]
                 dwg, dwu = dwgu[:FF], dwgu[FF:]
             del dgu
         else:
@@ -350,7 +352,7 @@ class LlamaLayerFn(torch.autograd.Function):
         # ---- attention
         ev = sd.fork()
         datt = ops.linear_dx(dh1, wo)
-        dwo = sd.dw(ev, dh1, att, wo) if need[10] else None
+        dwo = sd.dw(ev, dh1, att, wo, "o") if need[10] else None
         ldq = q.stride(0)
         if wqkv is not None:
             dqkv = torch.empty((M, 3 * D), dtype=q.dtype, device=q.device)
@@ -382,7 +384,7 @@ class LlamaLayerFn(torch.autograd.Function):
             else:
                 dy1 = ops.linear_dx(dqkv, wqkv)
             if need[7] or need[8] or need[9]:
-                dwqkv = sd.dw(ev, dqkv, y1, wqkv)              # [3D, D]
+                dwqkv = sd.dw(ev, dqkv, y1, wqkv, "qkv")          # [3D, D]
                 dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]
         else:
             dy1 = ops.linear_dx(dq, wq)
@@ -538,7 +540,7 @@ class LMHeadLossFn(torch.autograd.Function):
         sd = _DwSide(h2.device, M, D)                    # (see DW_SIDE: the [M, D] grad-input GEMM beside the grad-weight GEMM)
         ev = sd.fork()
         dy = ops.linear_dx(dlv, lm_w, dy_pad_zero=True)
-        dlm = sd.dw(ev, dlv, y, lm_w) if need[2] else None
+        dlm = sd.dw(ev, dlv, y, lm_w, "lm") if need[2] else None
         dh, dnw = ops.rmsnorm_bwd(dy, h2, norm_w, rstd, dw_out=ops.grad_dst(norm_w) if need[1] else None)
         sd.join()
         return dh.view(B, S, D), (dnw if need[1] else None), dlm, None, None
