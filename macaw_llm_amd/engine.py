@@ -104,8 +104,9 @@ FP8 = {"qkv": False, "align": False, "mlp": False}
 # returns, so gradient hooks, bucket collectives and the optimizer see finished gradients exactly as before.  Same
 # kernels on the same operands (the GEMM scratch is per stream, ops._workspace): results are bit-identical.
 # Measured (profiles/r06_dw_side_stream.txt): cfg 2 136.0 / 135.4 -> 131.0 / 130.1 ms per step (+3.9 %), cfg 3 (M = 4608:
-# 288 tiles, whose 32-tile tail already fills the chip as eighths) +-0 -- so "auto" (default) turns it on only where the
-# [M, D] grad-input GEMMs are less than one round.  MACAW_DW_STREAM = 0 | 1 | auto; DW_SIDE["on"] at run time
+# 288 tiles, whose 32-tile tail already fills the chip as eighths) +-0, cfg 5 (360 tiles) +0.7 % -- so "auto" (default) turns it
+# on where the [M, D] grad-input GEMMs are less than one round or end in a round between 1/8 and full.
+# MACAW_DW_STREAM = 0 | 1 | auto; DW_SIDE["on"] at run time
 # (bench.py switches it off for its instrumented last step: per-launch durations need serial launches).
 DW_SIDE = {"on": {"0": False, "1": True}.get(__import__("os").environ.get("MACAW_DW_STREAM", "auto"), "auto"), "streams": {},
            # which projections' pairs go out on two streams when it is on (A/B switch: MACAW_DW_PAIRS=o,qkv ...)
@@ -142,9 +143,15 @@ class _DwSide:
     def __init__(self, dev, M=0, D=0):
         self.side = None
         on = DW_SIDE["on"]
-        if on == "auto":
-            on = (dev.type == "cuda" and M >= 256 and
-                  ((M + 255) // 256) * ((D + 255) // 256) < torch.cuda.get_device_properties(dev).multi_processor_count)
+        if on == "auto" and dev.type == "cuda" and M >= 256:
+            # the [M, D] grad-input GEMMs leave CUs idle: less than one round of 256 x 256 tiles (cfg 2: 144 on 256 CUs,
+            # +3.9 %), or a last round between 1/8 and full (cfg 5: 18 x 20 = 360 = 256 + 104, +0.7 %); tails of <= 1/8
+            # of the CUs already run as eighth-tiles on the whole chip (cfg 3: 288 = 256 + 32, measured +-0 / -0.3 %)
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            tiles = ((M + 255) // 256) * ((D + 255) // 256)
+            on = tiles < cus or tiles % cus > cus // 8
+        elif on == "auto":
+            on = False
         # (inside a hipGraph capture every stream shares the device's ONE GEMM scratch: stay on the capture stream)
         if on and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
             st = DW_SIDE["streams"].get(dev)

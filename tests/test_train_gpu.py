@@ -664,6 +664,8 @@ def test_grad_weight_gemms_on_the_side_stream_change_no_bit(dev):
         assert engine._DwSide(dev, 2176, 4096).side is not None          # cfg 2: 9 x 16 = 144 tiles
         assert engine._DwSide(dev, 4608, 4096).side is None or cus > 288   # cfg 3: 288 tiles
         assert engine._DwSide(dev, 144, 4096).side is None                # one sample: skinny kernels, left alone
+        assert engine._DwSide(dev, 8192, 4096).side is None or cus != 256  # cfg 4: 512 tiles = two whole rounds
+        assert engine._DwSide(dev, 4608, 5120).side is not None or cus != 256   # cfg 5: 360 tiles = 256 + 104
     finally:
         engine.DW_SIDE["on"] = old
 
