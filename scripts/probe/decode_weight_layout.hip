@@ -69,6 +69,44 @@ __global__ __launch_bounds__(512) void stream_kernel(const bf16* __restrict__ W,
   }
 }
 
+// reads `bytes` of W with `gridDim.x` workgroups of 256 threads and throws them away (the Infinity Cache keeps them)
+__global__ __launch_bounds__(256) void touch_kernel(const uint4* __restrict__ W, long n16, unsigned* sink) {
+  unsigned acc = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+    const uint4 v = W[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x12345678u) *sink = acc;
+}
+
+// the chain with the first `frac` of matrix i + 1 touched on a second stream while matrix i is consumed
+float run_prefetch(const std::vector<bf16*>& Ws, const bf16* x, float* out, int N, int K, int reps, double frac, int pf_blocks) {
+  hipStream_t sa, sb; CK(hipStreamCreate(&sa)); CK(hipStreamCreate(&sb));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  std::vector<hipEvent_t> ev(Ws.size());
+  for (auto& e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  unsigned* sink = reinterpret_cast<unsigned*>(out) + 100000;
+  const long n16 = (long)((double)N * K * 2 * frac) / 16;
+  float best = 1e30f;
+  for (int r = 0; r < reps; ++r) {
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, sa));
+    for (size_t i = 0; i < Ws.size(); ++i) {
+      CK(hipEventRecord(ev[i], sa));                       // kernel i is about to start
+      if (i + 1 < Ws.size() && n16 > 0) {
+        CK(hipStreamWaitEvent(sb, ev[i], 0));
+        hipLaunchKernelGGL(touch_kernel, dim3(pf_blocks), dim3(256), 0, sb, reinterpret_cast<const uint4*>(Ws[i + 1]), n16, sink);
+      }
+      hipLaunchKernelGGL((stream_kernel<false, 3>), dim3(N / 16), dim3(512), 0, sa, Ws[i], x, out, N, K);
+    }
+    CK(hipEventRecord(e1, sa)); CK(hipEventSynchronize(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  return best / (float)Ws.size();
+}
+
 template <bool PACKED, int NBUF>
 float run(const std::vector<bf16*>& Ws, const bf16* x, float* out, int N, int K, int reps) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -98,6 +136,13 @@ int main() {
     const float a4 = run<false, 4>(Ws, x, out, N, K, 5), b4 = run<true, 4>(Ws, x, out, N, K, 5);
     printf("%d,%d,%.1f,%.2f,%.2f,%.2f,%.2f,%.2f,%.2f\n", N, K, bytes / 1e6, a * 1e3, bytes / (a * 1e-3) / 1e12, b * 1e3,
            bytes / (b * 1e-3) / 1e12, a4 * 1e3, b4 * 1e3);
+    // prefetch of the next matrix on a second stream: fraction x blocks -> us per launch of the chain
+    for (double frac : {0.0, 0.1, 0.25, 0.5})
+      for (int blocks : {64, 256}) {
+        if (frac == 0.0 && blocks != 64) continue;
+        const float c = run_prefetch(Ws, x, out, N, K, 5, frac, blocks);
+        printf("  prefetch frac %.2f blocks %d: %.2f us per launch (%.2f TB/s)\n", frac, blocks, c * 1e3, bytes / (c * 1e-3) / 1e12);
+      }
     for (auto& W : Ws) CK(hipFree(W));
   }
   return 0;
