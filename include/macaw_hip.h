@@ -392,6 +392,13 @@ int mk_fp8_quantize(const void* x, int64_t n, int32_t dtype, uint8_t* q, float* 
  * scales[r] = amax_r / 448 (1 for a zero row).  cols % 8 == 0; GEMM operands need cols % 128 == 0. */
 int mk_fp8_quantize_rows(const void* x, int32_t rows, int32_t cols, int64_t ld, int32_t dtype,
                          uint8_t* q, int64_t ldq, float* scales, void* stream);
+/* mk_rmsnorm_fwd (LlamaRMSNorm, modeling.py:311-319) with mk_fp8_quantize_rows of its output y folded in: h_out (with
+ * res), y, rstd as mk_rmsnorm_fwd writes them, plus q [rows, cols] e4m3 (pitch ldq) and scales[rows] of y -- the
+ * activation operand of the fp8 q|k|v GEMM (BASELINE cfg 5) without a second pass over y.  Bit-identical to the two
+ * calls.  bf16, cols % 8 == 0, cols <= 16384, contiguous rows, 16-byte aligned. */
+int mk_rmsnorm_fwd_fp8(const void* x, const void* res, const void* w, void* h_out, void* y, float* rstd,
+                       uint8_t* q, int64_t ldq, float* scales, int32_t rows, int32_t cols, float eps,
+                       int32_t dtype, void* stream);
 /* Per-COLUMN scaled e4m3 with TRANSPOSED output: qt[c, r] = e4m3(x[r, c] * 448 / amax_c),
  * scales[c] = amax_c / 448 -- the operand of the fp8 grad-input GEMM dx = dy W (the reduction runs
  * over the rows of W [out, in], modeling.py:159-162: nn.Linear stores [out, in]), i.e. W^T K-major

@@ -511,24 +511,114 @@ __global__ __launch_bounds__(256) void fp8_rowquant_reg_kernel(const bf16* x, lo
   }
 }
 
+// RMSNorm with the e4m3 row quantisation of its OUTPUT folded in (BASELINE cfg 5: y1 = RMSNorm(x) feeds the fp8 q|k|v
+// GEMM): the row stays in registers from the sum of squares to the quantised store -- y (bf16, for the bf16 grad-weight
+// GEMM), its e4m3 image and the row scale leave in one pass instead of rmsnorm_fwd + fp8_rowquant (which re-reads y).
+// Same arithmetic in the same order as rmsnorm_fwd_kernel (norm.hip: fp32 sum of squares per thread over chunks
+// tid, tid + 256, ..., block_sum, y = w * rnd(h * rstd)) and as fp8_rowquant_reg_kernel on the ROUNDED y: all four
+// outputs are bit-identical to the two launches (tests/test_fp8_gpu.py).
+template <int CH>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_fp8_kernel(const bf16* x, const bf16* res, const bf16* w, bf16* h_out,
+                                                              bf16* y, float* rstd_out, uint8_t* q, long ldq,
+                                                              float* scale, int cols, float eps) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const bf16* xr = x + row * cols;
+  const int nch = cols / 8;
+  float v[CH][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = threadIdx.x + 256 * k;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+    if (c < nch) {
+      VecIO<bf16>::load(xr + c * 8, v[k]);
+      if (res) {
+        float r[8];
+        VecIO<bf16>::load(res + row * cols + c * 8, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[k][e] = rnd<bf16>(v[k][e] + r[e]);
+        VecIO<bf16>::store(h_out + row * cols + c * 8, v[k]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += v[k][e] * v[k][e];
+    }
+  }
+  ss = block_sum<256>(ss, red);
+  const float rstd = rsqrtf(ss / (float)cols + eps);
+  if (threadIdx.x == 0) rstd_out[row] = rstd;
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = threadIdx.x + 256 * k;
+    if (c < nch) {
+      float g[8];
+      VecIO<bf16>::load(w + c * 8, g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[k][e] = rnd<bf16>(g[e] * rnd<bf16>(v[k][e] * rstd));
+        m = fmaxf(m, fabsf(v[k][e]));
+      }
+      VecIO<bf16>::store(y + row * cols + c * 8, v[k]);
+    }
+  }
+  m = block_max<256>(m, red);
+  const float sc = m > 0.f ? 448.f / m : 1.f;
+  if (threadIdx.x == 0) scale[row] = m > 0.f ? m / 448.f : 1.f;
+  uint8_t* qr = q + row * ldq;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = threadIdx.x + 256 * k;
+    if (c < nch) *reinterpret_cast<int2*>(qr + c * 8) = fp8_pack8(v[k], sc);
+  }
+}
+
 // ---- per-COLUMN scaled e4m3, TRANSPOSED output (the weight of a grad-input GEMM: dx = dy W reduces
 // over W's ROWS, so the fp8 MFMA wants W^T K-major with one scale per row of W^T = per column of W).
 // pass 1: amax[c] = max_r |x[r, c]| (row slabs, atomicMax on the bit pattern of a non-negative float)
 __global__ __launch_bounds__(256) void fp8_colamax_kernel(const bf16* x, long ld, int rows, int cols,
                                                           float* amax, int rows_per_block) {
-  const int c8 = blockIdx.x * 256 + threadIdx.x;          // this thread's group of 8 columns
-  if (c8 * 8 >= cols) return;
+  // a block = 256 columns (32 groups of 8, tx) x 8 row lanes (ty): a wave reads two 512-byte row segments per
+  // instruction; the 8 row lanes meet in LDS, ONE atomicMax per column and block.  (Round 3 gave a thread 8 columns of a
+  // 128-row slab: 360 blocks for a [15360, 5120] weight and 120 atomics per column -- 85 us = 1.8 TB/s, and smaller
+  // slabs made it slower, not faster: the atomics were the limit.  scripts/bench_fp8_weights.py)
+  __shared__ float red[8][256];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c8 = blockIdx.x * 32 + tx;                    // this thread's group of 8 columns
+  const bool live = c8 * 8 < cols;
+  const int cc = live ? c8 * 8 : 0;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
   float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int r = r0; r < r1; ++r) {
+  int r = r0 + ty;
+  for (; r + 24 < r1; r += 32) {                           // four rows of this lane requested before the first is used
+    uint4 raw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) raw[u] = VecIO<bf16>::load_raw(x + (long)(r + 8 * u) * ld + cc);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v[8];
+      VecIO<bf16>::unpack(raw[u], v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], fabsf(v[k]));
+    }
+  }
+  for (; r < r1; r += 8) {
     float v[8];
-    VecIO<bf16>::load(x + (long)r * ld + c8 * 8, v);
+    VecIO<bf16>::load(x + (long)r * ld + cc, v);
 #pragma unroll
     for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], fabsf(v[k]));
   }
 #pragma unroll
-  for (int k = 0; k < 8; ++k)
-    atomicMax(reinterpret_cast<unsigned int*>(amax) + c8 * 8 + k, __float_as_uint(m[k]));
+  for (int k = 0; k < 8; ++k) red[ty][tx * 8 + k] = m[k];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < cols) {
+    float mm = red[0][threadIdx.x];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) mm = fmaxf(mm, red[j][threadIdx.x]);
+    atomicMax(reinterpret_cast<unsigned int*>(amax) + c, __float_as_uint(mm));
+  }
 }
 // pass 2: qt[c, r] = e4m3(x[r, c] * 448 / amax[c]) for a 64 x 64 tile through LDS; scale[c] = amax[c] / 448
 __global__ __launch_bounds__(256) void fp8_quant_t_kernel(const bf16* x, long ld, int rows, int cols,
@@ -866,6 +956,27 @@ extern "C" int mk_fp8_quantize_rows(const void* x, int32_t rows, int32_t cols, i
   return mk_check_launch();
 }
 
+extern "C" int mk_rmsnorm_fwd_fp8(const void* x, const void* res, const void* w, void* h_out, void* y, float* rstd,
+                                  uint8_t* q, int64_t ldq, float* scales, int32_t rows, int32_t cols, float eps,
+                                  int32_t dtype, void* stream) {
+  if (!x || !w || !y || !rstd || !q || !scales || rows <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
+  if (res && !h_out) return MK_ERR_BAD_ARG;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(y) |
+                       reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(h_out);
+  if (dtype != MK_BF16 || (cols % 8) || (ldq % 8) || cols > 8 * 2048 || (al & 15) || (reinterpret_cast<uintptr_t>(q) & 7))
+    return MK_ERR_UNSUPPORTED;
+  const int ch = mk_cdiv(cols / 8, 256);
+#define MK_RF(CHV) MK_LAUNCH(rmsnorm_fwd_fp8_kernel<CHV>, dim3(rows), dim3(256), 0, MK_ST, (const bf16*)x, (const bf16*)res, \
+                             (const bf16*)w, (bf16*)h_out, (bf16*)y, rstd, q, (long)ldq, scales, cols, eps)
+  if (ch <= 1) MK_RF(1);
+  else if (ch <= 2) MK_RF(2);
+  else if (ch <= 3) MK_RF(3);
+  else if (ch <= 4) MK_RF(4);
+  else MK_RF(8);
+#undef MK_RF
+  return mk_check_launch();
+}
+
 extern "C" int mk_fp8_quantize_cols_t(const void* x, int32_t rows, int32_t cols, int64_t ld, int32_t dtype,
                                       uint8_t* qt, int64_t ldqt, float* scales, float* amax_ws, void* stream) {
   if (!x || !qt || !scales || !amax_ws || rows <= 0 || cols <= 0) return MK_ERR_BAD_ARG;
@@ -873,8 +984,9 @@ extern "C" int mk_fp8_quantize_cols_t(const void* x, int32_t rows, int32_t cols,
       (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(qt) & 7))
     return MK_ERR_UNSUPPORTED;
   MK_LAUNCH(fp8_zero_n_kernel, dim3(mk_cdiv(cols, 256)), dim3(256), 0, MK_ST, amax_ws, cols);
-  const int rpb = 128;
-  MK_LAUNCH(fp8_colamax_kernel, dim3(mk_cdiv(cols / 8, 256), mk_cdiv(rows, rpb)), dim3(256), 0, MK_ST,
+  // MK_FP8_COLAMAX_RPB: rows per block (sweep: scripts/bench_fp8_weights.py)
+  static const int rpb = [] { const char* e = getenv("MK_FP8_COLAMAX_RPB"); const int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
+  MK_LAUNCH(fp8_colamax_kernel, dim3(mk_cdiv(cols, 256), mk_cdiv(rows, rpb)), dim3(256), 0, MK_ST,
             (const bf16*)x, (long)ld, rows, cols, amax_ws, rpb);
   MK_LAUNCH(fp8_quant_t_kernel, dim3(mk_cdiv(cols, 64), mk_cdiv(rows, 64)), dim3(256), 0, MK_ST,
             (const bf16*)x, (long)ld, rows, cols, amax_ws, qt, (long)ldqt, scales);

@@ -242,7 +242,11 @@ class LlamaLayerFn(torch.autograd.Function):
         M, D = x2.shape
         H, hd = n_heads, D // n_heads
         FF = wg.shape[0]
-        _, y1, rstd1 = ops.rmsnorm_fwd(x2, ln1, eps)
+        fp8_qkv = wqkv is not None and FP8["qkv"] and x2.is_contiguous() and _fp8_ok(x2, wqkv)
+        if fp8_qkv:      # (y1's e4m3 image and row scales leave the RMSNorm kernel with it: one pass over the row)
+            _, y1, rstd1, y1q, y1s = ops.rmsnorm_fwd_fp8(x2, ln1, eps)
+        else:
+            _, y1, rstd1 = ops.rmsnorm_fwd(x2, ln1, eps)
         use_flash = flash_ok(x2.dtype, hd)
         # short sequences (ops.rope_fuse_mode): "bwd" -- q, k rotated by mk_rope as ever, only the backward kernel folds
         # the rotation of dq / dk back into its stores; "full" -- q, k stay UNROTATED in HBM, also as the tensors saved
@@ -250,8 +254,9 @@ class LlamaLayerFn(torch.autograd.Function):
         fuse = ops.rope_fuse_mode() if use_flash and ops.flash_rope_ok(hd, S, S, cos, x2) else "off"
         rope_in = (cos, sin, pos) if fuse == "full" else None
         if wqkv is not None:
-            if FP8["qkv"] and _fp8_ok(y1, wqkv):
-                qkv = _fp8_linear(y1, wqkv)                   # e4m3 x e4m3 -> bf16 (cfg 5)
+            if fp8_qkv:
+                wq8, ws8 = ops.fp8_weight(wqkv)
+                qkv = ops.linear_fp8(y1q, y1s, wq8, ws8)      # e4m3 x e4m3 -> bf16 (cfg 5)
             else:
                 qkv = ops.linear_fwd(y1, wqkv)                # [M, 3D]
             q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]

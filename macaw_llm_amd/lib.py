@@ -114,6 +114,7 @@ SIGNATURES = {
     "mk_adamw_multi": [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _i32, _vp],
     "mk_fp8_quantize": [_vp, _i64, _i32, _vp, _vp, _vp, _vp],
     "mk_fp8_quantize_rows": [_vp, _i32, _i32, _i64, _i32, _vp, _i64, _vp, _vp],
+    "mk_rmsnorm_fwd_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _f32, _i32, _vp],
     "mk_fp8_quantize_cols_t": [_vp, _i32, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mk_image_transform": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp],
     "mk_log_mel": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp],

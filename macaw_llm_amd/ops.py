@@ -325,6 +325,21 @@ def rmsnorm_fwd(x, w, eps, res=None):
     return h, y, rstd
 
 
+def rmsnorm_fwd_fp8(x, w, eps, res=None):
+    """rmsnorm_fwd + quantize_fp8_rows(y) in one pass over the row: returns (h, y, rstd, q uint8 [rows, cols],
+    scales f32 [rows]) -- bit-identical to the two calls"""
+    lib = _L.load()
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    h = torch.empty_like(x) if res is not None else x
+    q = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _L.check(lib.mk_rmsnorm_fwd_fp8(_p(x), _p(res), _p(w), _p(h) if res is not None else None, _p(y), _p(rstd),
+                                    _p(q), cols, _p(sc), rows, cols, eps, dt(x), _st()), "mk_rmsnorm_fwd_fp8")
+    return h, y, rstd, q, sc
+
+
 def rmsnorm_bwd(dy, h, w, rstd, dres=None, dw_out=None, dw_accumulate=False):
     """returns (dx, dw); dx = dres + d/dh, dw in w.dtype"""
     lib = _L.load()

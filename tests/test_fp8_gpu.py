@@ -235,3 +235,26 @@ def test_model_with_fp8_against_the_oracle_and_the_format_yardstick(dev, mlp):
     # switched off again: bit-identical to the first run
     again, _, _ = run()
     assert torch.equal(again, b_logits)
+
+
+@pytest.mark.parametrize("rows,cols,with_res", [(37, 5120, False), (64, 4096, True), (5, 512, False), (19, 8192, True),
+                                                (3, 12288, False), (33, 1544, True)])
+def test_rmsnorm_with_the_fp8_row_quantisation_folded_in_is_bit_identical(dev, rows, cols, with_res):
+    """mk_rmsnorm_fwd_fp8 (the row stays in registers from the sum of squares to the e4m3 store: what cfg 5's q|k|v GEMM
+    takes as its activation operand) against mk_rmsnorm_fwd followed by mk_fp8_quantize_rows: h, y, rstd, the e4m3 bytes
+    and the row scales BIT-IDENTICAL; every register-array size of the kernel (1, 2, 3, 4, 8 chunks per thread), a ragged
+    chunk count, a zero row (scale 1)."""
+    g = torch.Generator().manual_seed(rows * 13 + cols)
+    x = (torch.randn((rows, cols), generator=g) * 1.7).to(torch.bfloat16).to(dev)
+    x[rows // 2].zero_()
+    res = (torch.randn((rows, cols), generator=g)).to(torch.bfloat16).to(dev) if with_res else None
+    if with_res:
+        res[rows // 2].zero_()
+    w = (1.0 + 0.1 * torch.randn(cols, generator=g)).to(torch.bfloat16).to(dev)
+    h0, y0, r0 = ops.rmsnorm_fwd(x, w, 1e-6, res=res)
+    q0, s0 = ops.quantize_fp8_rows(y0)
+    h1, y1, r1, q1, s1 = ops.rmsnorm_fwd_fp8(x, w, 1e-6, res=res)
+    assert torch.equal(y1, y0) and torch.equal(r1, r0) and torch.equal(h1, h0)
+    assert torch.equal(q1, q0), (q1 != q0).sum().item()
+    assert torch.equal(s1, s0)
+    assert s1[rows // 2].item() == 1.0 and int(q1[rows // 2].max()) == 0
