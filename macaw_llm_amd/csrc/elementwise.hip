@@ -985,7 +985,7 @@ extern "C" int mk_fp8_quantize_cols_t(const void* x, int32_t rows, int32_t cols,
     return MK_ERR_UNSUPPORTED;
   MK_LAUNCH(fp8_zero_n_kernel, dim3(mk_cdiv(cols, 256)), dim3(256), 0, MK_ST, amax_ws, cols);
   // MK_FP8_COLAMAX_RPB: rows per block (sweep: scripts/bench_fp8_weights.py)
-  static const int rpb = [] { const char* e = getenv("MK_FP8_COLAMAX_RPB"); const int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
+  static const int rpb = [] { const char* e = getenv("MK_FP8_COLAMAX_RPB"); const int v = e ? atoi(e) : 64; return v > 0 ? v : 64; }();
   MK_LAUNCH(fp8_colamax_kernel, dim3(mk_cdiv(cols, 256), mk_cdiv(rows, rpb)), dim3(256), 0, MK_ST,
             (const bf16*)x, (long)ld, rows, cols, amax_ws, rpb);
   MK_LAUNCH(fp8_quant_t_kernel, dim3(mk_cdiv(cols, 64), mk_cdiv(rows, 64)), dim3(256), 0, MK_ST,

@@ -17,5 +17,5 @@ def bench(fn, iters=3):
 mb = Ws[0].numel() * 2 / 1e6
 tr = bench(lambda W: ops.quantize_fp8_rows(W))
 tc = bench(lambda W: ops.quantize_fp8_cols_t(W))
-print(f"MK_FP8_COLAMAX_RPB={os.environ.get('MK_FP8_COLAMAX_RPB', 'default')}: rows {tr:7.1f} us ({1.5 * mb / tr / 1e6:.2f} TB/s of 1.5 x {mb:.0f} MB)   "
-      f"cols_t {tc:7.1f} us ({2.5 * mb / tc / 1e6:.2f} TB/s of 2.5 x {mb:.0f} MB)   x 40 layers = {(tr + tc) * 40 / 1e3:.2f} ms per step")
+print(f"MK_FP8_COLAMAX_RPB={os.environ.get('MK_FP8_COLAMAX_RPB', 'default')}: rows {tr:7.1f} us ({1.5 * mb / tr:.2f} TB/s of 1.5 x {mb:.0f} MB)   "
+      f"cols_t {tc:7.1f} us ({2.5 * mb / tc:.2f} TB/s of 2.5 x {mb:.0f} MB)   x 40 layers = {(tr + tc) * 40 / 1e3:.2f} ms per step")
