@@ -137,21 +137,25 @@ def tower_side_stream(x, tower, other=True):
     return st
 
 
+def dw_side_auto(M: int, D: int, cus: int) -> bool:
+    """the "auto" rule of DW_SIDE: do the [M, D] grad-input GEMMs of a layer leave CUs idle?  Less than one round of
+    256 x 256 tiles (cfg 2: 9 x 16 = 144 on 256 CUs, +3.9 %), or a last round between 1/8 and full (cfg 5: 18 x 20 = 360 =
+    256 + 104, +0.7 %); tails of <= 1/8 of the CUs already run as eighth-tiles on the whole chip (cfg 3: 288 = 256 + 32,
+    measured +-0 / -0.3 %), whole rounds have nothing idle (cfg 4: 512); fewer than 256 rows take the skinny kernels"""
+    if M < 256:
+        return False
+    tiles = ((M + 255) // 256) * ((D + 255) // 256)
+    return tiles < cus or tiles % cus > cus // 8
+
+
 class _DwSide:
     """fork / launch / join of one layer's grad-weight GEMMs (no-op object when off)"""
 
     def __init__(self, dev, M=0, D=0):
         self.side = None
         on = DW_SIDE["on"]
-        if on == "auto" and dev.type == "cuda" and M >= 256:
-            # the [M, D] grad-input GEMMs leave CUs idle: less than one round of 256 x 256 tiles (cfg 2: 144 on 256 CUs,
-            # +3.9 %), or a last round between 1/8 and full (cfg 5: 18 x 20 = 360 = 256 + 104, +0.7 %); tails of <= 1/8
-            # of the CUs already run as eighth-tiles on the whole chip (cfg 3: 288 = 256 + 32, measured +-0 / -0.3 %)
-            cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            tiles = ((M + 255) // 256) * ((D + 255) // 256)
-            on = tiles < cus or tiles % cus > cus // 8
-        elif on == "auto":
-            on = False
+        if on == "auto":
+            on = dev.type == "cuda" and dw_side_auto(M, D, torch.cuda.get_device_properties(dev).multi_processor_count)
         # (inside a hipGraph capture every stream shares the device's ONE GEMM scratch: stay on the capture stream)
         if on and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
             st = DW_SIDE["streams"].get(dev)

@@ -153,3 +153,28 @@ def test_gradient_checkpointing_flag_surface():
     assert m.model.gradient_checkpointing is True
     m.gradient_checkpointing_disable()
     assert m.model.gradient_checkpointing is False
+
+
+def test_grad_weight_side_stream_auto_rule_and_switches(monkeypatch):
+    """engine.DW_SIDE "auto": the grad-weight GEMMs go to the second stream exactly where the [M, D] grad-input GEMMs leave
+    CUs idle (the four BASELINE training shapes on 256 CUs), never on the CPU engines; the RoPE-fusion switch takes its
+    three values and refuses anything else."""
+    from macaw_llm_amd import engine, ops
+    assert engine.dw_side_auto(2176, 4096, 256)          # cfg 2: 144 tiles, less than one round
+    assert not engine.dw_side_auto(4608, 4096, 256)      # cfg 3: 288 = 256 + 32 (the tail runs as eighth-tiles)
+    assert not engine.dw_side_auto(8192, 4096, 256)      # cfg 4: two whole rounds
+    assert engine.dw_side_auto(4608, 5120, 256)          # cfg 5: 360 = 256 + 104
+    assert not engine.dw_side_auto(144, 4096, 256)       # one sample: skinny kernels
+    import torch
+    sd = engine._DwSide(torch.device("cpu"), 2176, 4096)
+    assert sd.side is None and sd.fork() is None
+    sd.join()
+    for v in ("off", "bwd", "full"):
+        monkeypatch.setenv("MACAW_ROPE_FUSE", v)
+        assert ops.rope_fuse_mode() == v
+    monkeypatch.setenv("MACAW_ROPE_FUSE", "yes")
+    import pytest
+    with pytest.raises(ops.MacawHipError):
+        ops.rope_fuse_mode()
+    monkeypatch.delenv("MACAW_ROPE_FUSE")
+    assert ops.rope_fuse_mode() == "off"
