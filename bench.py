@@ -443,6 +443,7 @@ def main():
         if os.environ.get("MACAW_BENCH_VERBOSE") and rank == 0:
             print(f"[warmup] loss {float(l0.detach()):.4f}", file=sys.stderr)
     fence()
+    dw_side_used = False
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = i == args.steps - 1
@@ -452,6 +453,7 @@ def main():
             # steps overlap the per-bucket AdamW launches with the backward on one rank: BucketedStep.local_overlap)
             runtime.serial_update = True
             from macaw_llm_amd import engine as _engine
+            dw_side_used = bool(_engine.DW_SIDE["streams"])   # did the steps so far put grad-weight GEMMs on a second stream?
             _engine.DW_SIDE["on"] = False        # (grad-weight GEMMs back on the compute stream for this step, see engine.DW_SIDE)
             ops.prof_begin()
             runtime.profile_comm(True)
@@ -508,6 +510,9 @@ def main():
                        "step_launch": ("hipGraph replay of the whole step (train.GraphedStep); setup step and the "
                                        "last timed step eager (per-launch HIP events)") if graphed is not None
                                       else "eager, kernel by kernel",
+                       "grad_weight_side_stream": ("on except in the instrumented last step (engine.DW_SIDE auto: the [M, D] "
+                                                   "grad-input GEMMs leave CUs idle at this shape)") if dw_side_used
+                                                  else "off (engine.DW_SIDE auto)",
                        "setup_steps": 1, "activation_checkpointing": bool(spec["ckpt"]),
                        "peak_mem_gib": round(peak_mem, 1),
                        "loss": round(float(loss.detach()), 4)},
