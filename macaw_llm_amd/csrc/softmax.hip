@@ -352,6 +352,45 @@ MK_DEV void adam_store4(_Float16* p, const float (&o)[4]) {
   *reinterpret_cast<f16x4*>(p) = v;
 }
 MK_DEV void adam_store4(float* p, const float (&o)[4]) { VecIO<float>::store(p, o); }
+// the same with the NON-TEMPORAL hint, for the two streams of the multi-tensor kernel that are touched once per step
+// and not again before the next forward / backward has run through the caches: the gradient (read) and the 16-bit
+// parameter copy (written).  The fp32 state keeps plain accesses (all four streams non-temporal measured 4.0 TB/s in
+// rounds 1 and 3).  scripts/probe/adamw_stream.hip: +1.7 ... +2.7 % on its own, +4 ... +6 % with 4096-element slices.
+typedef unsigned int adam_u32x2 __attribute__((ext_vector_type(2)));
+typedef float adam_f32x4 __attribute__((ext_vector_type(4)));
+MK_DEV void adam_load4_nt(const bf16* p, float (&o)[4]) {
+  const bf16x4 v = __builtin_bit_cast(bf16x4, __builtin_nontemporal_load(reinterpret_cast<const adam_u32x2*>(p)));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (float)v[k];
+}
+MK_DEV void adam_load4_nt(const _Float16* p, float (&o)[4]) {
+  const f16x4 v = __builtin_bit_cast(f16x4, __builtin_nontemporal_load(reinterpret_cast<const adam_u32x2*>(p)));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (float)v[k];
+}
+MK_DEV void adam_load4_nt(const float* p, float (&o)[4]) {
+  const adam_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const adam_f32x4*>(p));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = v[k];
+}
+MK_DEV void adam_store4_nt(bf16* p, const float (&o)[4]) {
+  bf16x4 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = (bf16)o[k];
+  __builtin_nontemporal_store(__builtin_bit_cast(adam_u32x2, v), reinterpret_cast<adam_u32x2*>(p));
+}
+MK_DEV void adam_store4_nt(_Float16* p, const float (&o)[4]) {
+  f16x4 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = (_Float16)o[k];
+  __builtin_nontemporal_store(__builtin_bit_cast(adam_u32x2, v), reinterpret_cast<adam_u32x2*>(p));
+}
+MK_DEV void adam_store4_nt(float* p, const float (&o)[4]) {
+  adam_f32x4 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = o[k];
+  __builtin_nontemporal_store(v, reinterpret_cast<adam_f32x4*>(p));
+}
 
 // 16-byte vector form: N = 8 (bf16) / 4 (fp32) parameters per thread and iteration
 // (28 B/param of HBM traffic: the kernel is a pure stream, cdna_hip_programming.md G13).
@@ -371,7 +410,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* param, float* master, flo
   for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long)gridDim.x * 256) {
     const long i0 = c * N;
     float g[N], w[N], mi[N], vi[N];
-    adam_load4(grad + i0, g);
+    adam_load4_nt(grad + i0, g);
     VecIO<float>::load(master + i0, w);
     VecIO<float>::load(m + i0, mi);
     VecIO<float>::load(v + i0, vi);
@@ -388,7 +427,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* param, float* master, flo
     VecIO<float>::store(master + i0, w);
     VecIO<float>::store(m + i0, mi);
     VecIO<float>::store(v + i0, vi);
-    adam_store4(param + i0, w);
+    adam_store4_nt(param + i0, w);
   }
   for (long i = nch * N + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float g = to_f32<T>(grad[i]) * gscale;
@@ -409,7 +448,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* param, float* master, flo
 // owns one MK_ADAMW_CHUNK-element slice of one tensor, found by binary search in the chunk
 // prefix; per-element arithmetic is exactly adamw_kernel's.
 struct AdamItem { void* param; float* master; float* m; float* v; const void* grad; long n; };
-constexpr long MK_ADAMW_CHUNK = 32768;
+// Slice size (round 6, scripts/probe/adamw_stream.hip): 32768-element slices left the ~2000 resident blocks spread over
+// 2000 x 128 KiB of each of the eight streams; with 4096 the blocks in flight cover a window an eighth as wide (consecutive
+// block ids = consecutive slices) and the stream gains 4-6 % on both a slow (5.54 -> 5.88 TB/s) and a fast box (6.08 -> 6.31),
+// together with the non-temporal hints above.  mk_adamw_chunk() tells the host which slice size its chunk table must use.
+#ifndef MK_ADAMW_CHUNK_ELEMS
+#define MK_ADAMW_CHUNK_ELEMS 4096
+#endif
+constexpr long MK_ADAMW_CHUNK = MK_ADAMW_CHUNK_ELEMS;
 
 template <typename T>
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamItem* items, const long* chunk_start,
@@ -439,8 +485,8 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamItem* items,
     const bool two = i1 < vec_end;             // (a chunk is 32768 elements: true except on a ragged tail)
     const long j1 = two ? i1 : i0;
     float g0[N], w0[N], m0[N], v0[N], g1[N], w1[N], m1[N], v1[N];
-    adam_load4(grad + i0, g0);
-    adam_load4(grad + j1, g1);
+    adam_load4_nt(grad + i0, g0);
+    adam_load4_nt(grad + j1, g1);
     VecIO<float>::load(it.master + i0, w0);
     VecIO<float>::load(it.master + j1, w1);
     VecIO<float>::load(it.m + i0, m0);
@@ -460,7 +506,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamItem* items,
     VecIO<float>::store(it.master + i0, w0);
     VecIO<float>::store(it.m + i0, m0);
     VecIO<float>::store(it.v + i0, v0);
-    adam_store4(param + i0, w0);
+    adam_store4_nt(param + i0, w0);
     if (two) {
 #pragma unroll
       for (int k = 0; k < N; ++k) {
@@ -475,7 +521,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamItem* items,
       VecIO<float>::store(it.master + i1, w1);
       VecIO<float>::store(it.m + i1, m1);
       VecIO<float>::store(it.v + i1, v1);
-      adam_store4(param + i1, w1);
+      adam_store4_nt(param + i1, w1);
     }
   }
   for (long i = vec_end + threadIdx.x; i < end; i += 256) {
@@ -687,6 +733,8 @@ extern "C" int mk_argmax_rows(const void* x, int64_t ld, int32_t rows, int32_t c
   else return MK_ERR_UNSUPPORTED;
   return mk_check_launch();
 }
+
+extern "C" int mk_adamw_chunk(void) { return (int)MK_ADAMW_CHUNK; }
 
 extern "C" int mk_adamw_multi(const void* items, const int64_t* chunk_start, int32_t n_items,
                               int64_t n_chunks, float lr, float beta1, float beta2, float eps,

@@ -109,6 +109,7 @@ SIGNATURES = {
     "mk_decode_attn": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64,
                        _i64, _f32, _i32, _vp],
     "mk_adamw_set_max_blocks": [_i32],
+    "mk_adamw_chunk": [],
     "mk_adamw": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _i32,
                  _vp],
     "mk_adamw_multi": [_vp, _vp, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _i32, _vp],

@@ -255,7 +255,16 @@ class FusedAdamW(torch.optim.Optimizer):
                    self.step_count, grad_scale)
 
     # ---- multi-tensor form ------------------------------------------------------------------
-    _CHUNK = 32768           # elements per workgroup slice (MK_ADAMW_CHUNK in csrc/softmax.hip)
+    @property
+    def _CHUNK(self) -> int:
+        """elements per workgroup slice of the multi-tensor kernel: the library says (mk_adamw_chunk, csrc/softmax.hip)"""
+        c = FusedAdamW._chunk_cache
+        if c is None:
+            from . import lib as _L
+            c = FusedAdamW._chunk_cache = int(_L.load().mk_adamw_chunk())
+        return c
+
+    _chunk_cache = None
 
     @torch.no_grad()
     def step_params(self, params, grad_scale: float = 1.0):
