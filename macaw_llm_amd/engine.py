@@ -15,6 +15,7 @@ tensor is ~42 MB per layer; a fused flash kernel for S = 2048 (cfg 4) is a later
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -108,15 +109,15 @@ FP8 = {"qkv": False, "align": False, "mlp": False}
 # on where the [M, D] grad-input GEMMs are less than one round or end in a round between 1/8 and full.
 # MACAW_DW_STREAM = 0 | 1 | auto; DW_SIDE["on"] at run time
 # (bench.py switches it off for its instrumented last step: per-launch durations need serial launches).
-DW_SIDE = {"on": {"0": False, "1": True}.get(__import__("os").environ.get("MACAW_DW_STREAM", "auto"), "auto"), "streams": {},
+DW_SIDE = {"on": {"0": False, "1": True}.get(os.environ.get("MACAW_DW_STREAM", "auto"), "auto"), "streams": {},
            # which projections' pairs go out on two streams when it is on (A/B switch: MACAW_DW_PAIRS=o,qkv ...)
-           "pairs": set((__import__("os").environ.get("MACAW_DW_PAIRS") or "down,gu,o,qkv,lm").split(","))}
+           "pairs": set((os.environ.get("MACAW_DW_PAIRS") or "down,gu,o,qkv,lm").split(","))}
 
 
 # Frozen audio tower on a second stream beside the image / video tower (experiment, MACAW_ENC_STREAMS=1; off by default):
 # cfg 3 218.4 / 218.4 -> 217.6 / 217.3 ms per step (+0.4 %, profiles/r06_dw_side_stream.txt "towers") -- inside the
 # box-to-box spread, so the default keeps one stream there.
-ENC_SIDE = {"on": bool(__import__("os").environ.get("MACAW_ENC_STREAMS")), "streams": {}}
+ENC_SIDE = {"on": bool(os.environ.get("MACAW_ENC_STREAMS")), "streams": {}}
 
 
 def tower_side_stream(x, tower, other=True):
