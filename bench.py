@@ -455,6 +455,7 @@ def main():
             from macaw_llm_amd import engine as _engine
             dw_side_used = bool(_engine.DW_SIDE["streams"])   # did the steps so far put grad-weight GEMMs on a second stream?
             _engine.DW_SIDE["on"] = False        # (grad-weight GEMMs back on the compute stream for this step, see engine.DW_SIDE)
+            _engine.ENC_SIDE["on"] = False       # (and the audio tower behind the image tower: one stream)
             ops.prof_begin()
             runtime.profile_comm(True)
         loss = step(eager=last)

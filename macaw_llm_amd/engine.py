@@ -114,10 +114,11 @@ DW_SIDE = {"on": {"0": False, "1": True}.get(os.environ.get("MACAW_DW_STREAM", "
            "pairs": set((os.environ.get("MACAW_DW_PAIRS") or "down,gu,o,qkv,lm").split(","))}
 
 
-# Frozen audio tower on a second stream beside the image / video tower (experiment, MACAW_ENC_STREAMS=1; off by default):
-# cfg 3 218.4 / 218.4 -> 217.6 / 217.3 ms per step (+0.4 %, profiles/r06_dw_side_stream.txt "towers") -- inside the
-# box-to-box spread, so the default keeps one stream there.
-ENC_SIDE = {"on": bool(os.environ.get("MACAW_ENC_STREAMS")), "streams": {}}
+# Frozen audio tower on a second stream beside the image / video tower (MACAW_ENC_STREAMS = 1 (default) | 0): the towers are
+# independent until the prefix is assembled, and their short-K GEMMs / 4-wave attention leave CUs idle between rounds.
+# cfg 3, alternated on one box: 218.4 / 218.4 -> 217.6 / 217.3 ms per step (+0.4-0.5 %, profiles/r06_dw_side_stream.txt
+# "towers"); outputs bit-identical (same kernels, same operands).  bench.py switches it off for its instrumented last step.
+ENC_SIDE = {"on": os.environ.get("MACAW_ENC_STREAMS", "1") != "0", "streams": {}}
 
 
 def tower_side_stream(x, tower, other=True):

@@ -763,8 +763,8 @@ class MM_LLMs(PreTrainedModel):
         audio_f, audio_side = None, None
         if inputs.get("audios") is not None:
             # The towers are independent of each other: with frozen encoders (run_clm_llms.py:390-393) the audio tower
-            # goes out on a second stream beside the image / video tower (experiment, MACAW_ENC_STREAMS=1; their
-            # short-K GEMMs and 4-wave attention leave CUs idle between rounds)
+            # goes out on a second stream beside the image / video tower (engine.ENC_SIDE; their short-K GEMMs and 4-wave
+            # attention leave CUs idle between rounds: +0.4 % of the cfg-3 step)
             audio_side = eng.tower_side_stream(inputs["audios"], self.audio_encoder,
                                                other=inputs.get("images") is not None or inputs.get("videos") is not None)
             if audio_side is not None:

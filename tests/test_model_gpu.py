@@ -401,3 +401,41 @@ def test_fp16_training_with_the_dynamic_loss_scale_of_the_reference_recipe(dev):
     assert all(math.isfinite(x) for x in losses) and losses[-1] < losses[n_skip] - 0.05, losses
     assert all(torch.isfinite(p).all() for p in params)
 
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_audio_tower_on_its_own_stream_changes_no_bit(dev, fuse):
+    """engine.ENC_SIDE (default on): from the SECOND forward of a model on, the frozen audio tower runs on a second stream
+    beside the image / video towers (the first forward stays on one stream: it re-homes the towers' q / k / v parameters).
+    Same kernels on the same operands: logits, loss and every gradient bit-identical to the one-stream forward, in eval and
+    in train mode (dropout seeds advance per step: compared step by step)."""
+    from macaw_llm_amd import engine
+    fx = load_case("micro_all")
+    cfg = configs.get(fx["config_name"])
+    inp = to_dev(fx["inputs"], dev)
+    res = {}
+    old = engine.ENC_SIDE["on"]
+    try:
+        for on in (False, True):
+            engine.ENC_SIDE["on"] = on
+            engine.ENC_SIDE["streams"].clear()
+            model = build_model(cfg, fx["state"], torch.bfloat16, dev, fuse=fuse).eval()
+            outs = []
+            for step in range(3):
+                model.zero_grad(set_to_none=True)
+                out = model(inputs=inp)
+                out.loss.backward()
+                grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+                outs.append((out.logits.detach().clone(), out.loss.detach().clone(), grads))
+            torch.cuda.synchronize()
+            res[on] = outs
+            if on:
+                assert engine.ENC_SIDE["streams"], "the audio tower never left the compute stream"
+                assert getattr(model.audio_encoder, "_macaw_side_warm", False)
+            else:
+                assert not engine.ENC_SIDE["streams"]
+    finally:
+        engine.ENC_SIDE["on"] = old
+    for (l0, s0, g0), (l1, s1, g1) in zip(res[False], res[True]):
+        assert torch.equal(l0, l1) and torch.equal(s0, s1)
+        assert g0.keys() == g1.keys() and all(torch.equal(g0[n], g1[n]) for n in g0)
