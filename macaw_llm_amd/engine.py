@@ -114,11 +114,12 @@ DW_SIDE = {"on": {"0": False, "1": True}.get(os.environ.get("MACAW_DW_STREAM", "
            "pairs": set((os.environ.get("MACAW_DW_PAIRS") or "down,gu,o,qkv,lm").split(","))}
 
 
-# Frozen audio tower on a second stream beside the image / video tower (MACAW_ENC_STREAMS = 1 (default) | 0): the towers are
+# Frozen audio tower on a second stream beside the image / video tower (MACAW_ENC_STREAMS = 1; off by default): the towers are
 # independent until the prefix is assembled, and their short-K GEMMs / 4-wave attention leave CUs idle between rounds.
-# cfg 3, alternated on one box: 218.4 / 218.4 -> 217.6 / 217.3 ms per step (+0.4-0.5 %, profiles/r06_dw_side_stream.txt
-# "towers"); outputs bit-identical (same kernels, same operands).  bench.py switches it off for its instrumented last step.
-ENC_SIDE = {"on": os.environ.get("MACAW_ENC_STREAMS", "1") != "0", "streams": {}}
+# cfg 3, alternated in fresh processes: one box 218.4 / 218.4 -> 217.6 / 217.3 ms per step (+0.4-0.5 %), another 207.5 / 207.8 ->
+# 207.6 / 207.5 (+-0) (profiles/r06_dw_side_stream.txt "towers"): inside the noise, so the default keeps one stream.
+# Outputs bit-identical (tests/test_model_gpu.py); bench.py switches it off for its instrumented last step.
+ENC_SIDE = {"on": os.environ.get("MACAW_ENC_STREAMS", "0") == "1", "streams": {}}
 
 
 def tower_side_stream(x, tower, other=True):

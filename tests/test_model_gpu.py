@@ -405,7 +405,7 @@ def test_fp16_training_with_the_dynamic_loss_scale_of_the_reference_recipe(dev):
 
 @pytest.mark.parametrize("fuse", [False, True])
 def test_audio_tower_on_its_own_stream_changes_no_bit(dev, fuse):
-    """engine.ENC_SIDE (default on): from the SECOND forward of a model on, the frozen audio tower runs on a second stream
+    """engine.ENC_SIDE (a switch, off by default: measured +0.4 % / +-0): from the SECOND forward of a model on, the frozen audio tower runs on a second stream
     beside the image / video towers (the first forward stays on one stream: it re-homes the towers' q / k / v parameters).
     Same kernels on the same operands: logits, loss and every gradient bit-identical to the one-stream forward, in eval and
     in train mode (dropout seeds advance per step: compared step by step)."""
