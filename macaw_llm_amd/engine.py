@@ -249,7 +249,7 @@ class LlamaLayerFn(torch.autograd.Function):
         M, D = x2.shape
         H, hd = n_heads, D // n_heads
         FF = wg.shape[0]
-        fp8_qkv = wqkv is not None and FP8["qkv"] and x2.is_contiguous() and _fp8_ok(x2, wqkv)
+        fp8_qkv = (wqkv is not None and FP8["qkv"] and x2.is_contiguous() and x2.shape[1] <= 16384 and _fp8_ok(x2, wqkv))
         if fp8_qkv:      # (y1's e4m3 image and row scales leave the RMSNorm kernel with it: one pass over the row)
             _, y1, rstd1, y1q, y1s = ops.rmsnorm_fwd_fp8(x2, ln1, eps)
         else:
