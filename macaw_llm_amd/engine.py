@@ -137,6 +137,7 @@ def tower_side_stream(x, tower, other=True):
     st = ENC_SIDE["streams"].get(x.device)
     if st is None:
         st = ENC_SIDE["streams"][x.device] = torch.cuda.Stream(device=x.device)
+    ENC_SIDE["launches"] = ENC_SIDE.get("launches", 0) + 1
     return st
 
 
@@ -180,6 +181,7 @@ class _DwSide:
             t.record_stream(self.side)       # (the allocator must not hand these blocks out before the side GEMM ran)
         out.record_stream(self.main)         # (a fresh `out` comes from the side stream's pool and is read on the main one)
         self.used = True
+        DW_SIDE["launches"] = DW_SIDE.get("launches", 0) + 1      # (for the tests: did anything go through the side stream?)
         return out
 
     def join(self):

@@ -35,6 +35,27 @@ def poison_allocator(big_mib: int = 768, small_blocks: int = 512):
     mids = [torch.full((2 << 20,), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(32)]
     torch.cuda.synchronize()
     del big, smalls, mids
+    poison_side_streams(min(big_mib, 256), min(small_blocks, 128))
+
+
+def poison_side_streams(big_mib: int = 256, small_blocks: int = 128):
+    """the same for the pools of the engine's SIDE streams (engine.DW_SIDE / ENC_SIDE: the caching allocator keeps one pool
+    per stream, and what a side-stream launch allocates -- a fresh grad-weight output, that stream's GEMM scratch -- comes
+    out of memory the main pool's poison never touched).  The streams are created here if they do not exist yet, so that
+    the first backward finds poisoned pools."""
+    import torch
+    from macaw_llm_amd import engine
+    dev = torch.device("cuda", torch.cuda.current_device())
+    for reg in (engine.DW_SIDE["streams"], engine.ENC_SIDE["streams"]):
+        st = reg.get(dev)
+        if st is None:
+            st = reg[dev] = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            big = torch.full((big_mib << 19,), float("nan"), dtype=torch.bfloat16, device="cuda")
+            smalls = [torch.full((64 << 10,), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(small_blocks)]
+            mids = [torch.full((2 << 20,), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(16)]
+        st.synchronize()
+        del big, smalls, mids
 
 
 @pytest.fixture(autouse=True)

@@ -647,9 +647,9 @@ def test_grad_weight_gemms_on_the_side_stream_change_no_bit(dev):
         engine.DW_SIDE["on"] = False
         l_ref, p_ref, _ = _run_bucketed(dev, fx, cfg, 4)
         engine.DW_SIDE["on"] = True
-        engine.DW_SIDE["streams"].clear()
+        engine.DW_SIDE["launches"] = 0
         l_side, p_side, _ = _run_bucketed(dev, fx, cfg, 4)
-        assert engine.DW_SIDE["streams"], "the side stream was never created: no grad-weight GEMM went through it"
+        assert engine.DW_SIDE["launches"] > 0, "no grad-weight GEMM went through the side stream"
         l_both, p_both, _ = _run_bucketed(dev, fx, cfg, 4, local_overlap=True)
     finally:
         engine.DW_SIDE["on"] = old
