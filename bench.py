@@ -463,6 +463,17 @@ def main():
     dt = time.perf_counter() - t0
     comm = runtime.comm_report()
     runtime.profile_comm(False)
+    digest = None
+    if os.environ.get("MACAW_BENCH_DIGEST") and rank == 0:
+        # (after the timed region) sha1 over the trained LLaMA layer 0 / last layer / lm_head weights and the exact loss bits: two
+        # runs that must be bit-identical (e.g. MACAW_DW_STREAM=0 against 1) are compared on this
+        import hashlib
+        hsh = hashlib.sha1()
+        for n, p in model.named_parameters():
+            if p.requires_grad and (".layers.0." in n or f".layers.{len(model.llm.model.layers) - 1}." in n or "lm_head" in n):
+                hsh.update(n.encode())
+                hsh.update(p.detach().view(torch.int16 if p.element_size() == 2 else torch.int32).cpu().numpy().tobytes())
+        digest = {"params_sha1": hsh.hexdigest(), "loss_hex": float(loss.detach()).hex()}
     if os.environ.get("MACAW_GEMM_REPORT") and rank == 0:
         ops.prof_report(os.environ["MACAW_GEMM_REPORT"])
     att_f, att_b, gemm8 = ops.prof_sum(1), ops.prof_sum(2), ops.prof_sum(3)
@@ -516,7 +527,8 @@ def main():
                                                   else "off (engine.DW_SIDE auto)",
                        "setup_steps": 1, "activation_checkpointing": bool(spec["ckpt"]),
                        "peak_mem_gib": round(peak_mem, 1),
-                       "loss": round(float(loss.detach()), 4)},
+                       "loss": round(float(loss.detach()), 4),
+                       **({"digest": digest} if digest else {})},
             "roofline": {"bound": "mfma", "kernel": "all mk_gemm launches of the step: gemm_bf16_v7_kernel (256x256, 8 waves, "
                                                     "csrc/gemm_v7.hip; its <.., FP8> instantiation for e4m3 operands) + "
                                                     "gemm_bf16_v9_kernel (256x256, 4 waves, generated inline-asm K loop, "
