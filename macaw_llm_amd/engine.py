@@ -192,6 +192,8 @@ class _DwSide:
 
     def join(self):
         if self.side is not None and self.used:
+            if os.environ.get("MACAW_DW_JOIN_SYNC"):      # diagnosis only: a HOST wait instead of the stream-ordered one
+                self.side.synchronize()
             self.main.wait_stream(self.side)
 
 
