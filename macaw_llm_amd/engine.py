@@ -180,12 +180,16 @@ class _DwSide:
     def dw(self, ev, dy, x, w, pair=None):
         if self.side is None or (pair is not None and pair not in DW_SIDE["pairs"]):
             return ops.linear_dw(dy, x, w=w)
+        # the destination comes from the COMPUTE stream's pool (a bucket slot, or a fresh tensor allocated here, outside the
+        # side-stream context): everything that reads the gradient later lives on that stream or synchronises with it
+        out = ops.grad_dst(w)
+        if out is None:
+            out = torch.empty((dy.shape[1], x.shape[1]), dtype=dy.dtype, device=dy.device)
         self.side.wait_event(ev)
         with torch.cuda.stream(self.side):
-            out = ops.linear_dw(dy, x, w=w)
-        for t in (dy, x):
+            ops.linear_dw(dy, x, out=out)
+        for t in (dy, x, out):
             t.record_stream(self.side)       # (the allocator must not hand these blocks out before the side GEMM ran)
-        out.record_stream(self.main)         # (a fresh `out` comes from the side stream's pool and is read on the main one)
         self.used = True
         DW_SIDE["launches"] = DW_SIDE.get("launches", 0) + 1      # (for the tests: did anything go through the side stream?)
         return out
