@@ -356,6 +356,8 @@ MK_DEV void adam_store4(float* p, const float (&o)[4]) { VecIO<float>::store(p, 
 // and not again before the next forward / backward has run through the caches: the gradient (read) and the 16-bit
 // parameter copy (written).  The fp32 state keeps plain accesses (all four streams non-temporal measured 4.0 TB/s in
 // rounds 1 and 3).  scripts/probe/adamw_stream.hip: +1.7 ... +2.7 % on its own, +4 ... +6 % with 4096-element slices.
+// Only in the multi-tensor kernel (the one-rank update, nothing reads its output before the next forward); the per-slice
+// kernel below, whose 16-bit output an all-gather picks up right behind it, keeps plain accesses.
 typedef unsigned int adam_u32x2 __attribute__((ext_vector_type(2)));
 typedef float adam_f32x4 __attribute__((ext_vector_type(4)));
 MK_DEV void adam_load4_nt(const bf16* p, float (&o)[4]) {
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* param, float* master, flo
   for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long)gridDim.x * 256) {
     const long i0 = c * N;
     float g[N], w[N], mi[N], vi[N];
-    adam_load4_nt(grad + i0, g);
+    adam_load4(grad + i0, g);      // (plain accesses here: this kernel's output feeds a collective, see adam_load4_nt)
     VecIO<float>::load(master + i0, w);
     VecIO<float>::load(m + i0, mi);
     VecIO<float>::load(v + i0, vi);
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* param, float* master, flo
     VecIO<float>::store(master + i0, w);
     VecIO<float>::store(m + i0, mi);
     VecIO<float>::store(v + i0, vi);
-    adam_store4_nt(param + i0, w);
+    adam_store4(param + i0, w);
   }
   for (long i = nch * N + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float g = to_f32<T>(grad[i]) * gscale;
