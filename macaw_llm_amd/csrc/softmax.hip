@@ -352,12 +352,13 @@ MK_DEV void adam_store4(_Float16* p, const float (&o)[4]) {
   *reinterpret_cast<f16x4*>(p) = v;
 }
 MK_DEV void adam_store4(float* p, const float (&o)[4]) { VecIO<float>::store(p, o); }
-// the same with the NON-TEMPORAL hint, for the two streams of the multi-tensor kernel that are touched once per step
-// and not again before the next forward / backward has run through the caches: the gradient (read) and the 16-bit
-// parameter copy (written).  The fp32 state keeps plain accesses (all four streams non-temporal measured 4.0 TB/s in
-// rounds 1 and 3).  scripts/probe/adamw_stream.hip: +1.7 ... +2.7 % on its own, +4 ... +6 % with 4096-element slices.
-// Only in the multi-tensor kernel (the one-rank update, nothing reads its output before the next forward); the per-slice
-// kernel below, whose 16-bit output an all-gather picks up right behind it, keeps plain accesses.
+// the same with the NON-TEMPORAL hint: used for the GRADIENT of the multi-tensor kernel only (read once per step, written by
+// GEMM kernels of this device long before).  scripts/probe/adamw_stream.hip: the hinted loads are worth +1.2 ... +2.2 % of the
+// stream; hinted stores of the 16-bit parameter copy added +0.3 % in the harness and are NOT used: with them in the per-slice
+// kernel (whose output an all-gather stages through the copy engine right behind it) the retired runtime's world-2 test came out
+// with one stale ZeRO-1 slice in 3 of 10 full-suite runs beside a busy second stream, and in 0 of 5 without them
+// (profiles/r06_dw_side_stream.txt "World 2") -- a store nobody must read late is not worth one somebody reads early.
+// (All four fp32 streams non-temporal measured 4.0 TB/s in rounds 1 and 3.)
 typedef unsigned int adam_u32x2 __attribute__((ext_vector_type(2)));
 typedef float adam_f32x4 __attribute__((ext_vector_type(4)));
 MK_DEV void adam_load4_nt(const bf16* p, float (&o)[4]) {
@@ -374,24 +375,6 @@ MK_DEV void adam_load4_nt(const float* p, float (&o)[4]) {
   const adam_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const adam_f32x4*>(p));
 #pragma unroll
   for (int k = 0; k < 4; ++k) o[k] = v[k];
-}
-MK_DEV void adam_store4_nt(bf16* p, const float (&o)[4]) {
-  bf16x4 v;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = (bf16)o[k];
-  __builtin_nontemporal_store(__builtin_bit_cast(adam_u32x2, v), reinterpret_cast<adam_u32x2*>(p));
-}
-MK_DEV void adam_store4_nt(_Float16* p, const float (&o)[4]) {
-  f16x4 v;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = (_Float16)o[k];
-  __builtin_nontemporal_store(__builtin_bit_cast(adam_u32x2, v), reinterpret_cast<adam_u32x2*>(p));
-}
-MK_DEV void adam_store4_nt(float* p, const float (&o)[4]) {
-  adam_f32x4 v;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = o[k];
-  __builtin_nontemporal_store(v, reinterpret_cast<adam_f32x4*>(p));
 }
 
 // 16-byte vector form: N = 8 (bf16) / 4 (fp32) parameters per thread and iteration
@@ -508,7 +491,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamItem* items,
     VecIO<float>::store(it.master + i0, w0);
     VecIO<float>::store(it.m + i0, m0);
     VecIO<float>::store(it.v + i0, v0);
-    adam_store4_nt(param + i0, w0);
+    adam_store4(param + i0, w0);
     if (two) {
 #pragma unroll
       for (int k = 0; k < N; ++k) {
@@ -523,7 +506,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamItem* items,
       VecIO<float>::store(it.master + i1, w1);
       VecIO<float>::store(it.m + i1, m1);
       VecIO<float>::store(it.v + i1, v1);
-      adam_store4_nt(param + i1, w1);
+      adam_store4(param + i1, w1);
     }
   }
   for (long i = vec_end + threadIdx.x; i < end; i += 256) {
