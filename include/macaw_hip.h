@@ -439,8 +439,8 @@ int mk_log_mel(const float* audio, int64_t ld, int32_t n_clips, int32_t n_sample
 /* Multi-tensor AdamW: one launch for a whole list of tensors (same arithmetic per element as
  * mk_adamw).  items: DEVICE array of n_items records {param, master, m, v, grad, n} (6 x 8 bytes,
  * every pointer 16-byte aligned); chunk_start: DEVICE int64[n_items + 1], prefix sum of
- * ceil(n / mk_adamw_chunk()) per item; n_chunks = chunk_start[n_items] (= grid size).  The gradient is read and the
- * 16-bit parameter copy written with the non-temporal hint (each is touched once per step). */
+ * ceil(n / mk_adamw_chunk()) per item; n_chunks = chunk_start[n_items] (= grid size).  The gradient is read with the
+ * non-temporal hint (touched once per step); every store is a plain one. */
 /* elements per workgroup slice of mk_adamw_multi / _dev: chunk_start[i] = sum over items j < i of ceil(n_j / mk_adamw_chunk()) */
 int mk_adamw_chunk(void);
 int mk_adamw_multi(const void* items, const int64_t* chunk_start, int32_t n_items, int64_t n_chunks,

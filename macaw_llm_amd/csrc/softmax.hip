@@ -436,7 +436,7 @@ struct AdamItem { void* param; float* master; float* m; float* v; const void* gr
 // Slice size (round 6, scripts/probe/adamw_stream.hip): 32768-element slices left the ~2000 resident blocks spread over
 // 2000 x 128 KiB of each of the eight streams; with 4096 the blocks in flight cover a window an eighth as wide (consecutive
 // block ids = consecutive slices) and the stream gains 4-6 % on both a slow (5.54 -> 5.88 TB/s) and a fast box (6.08 -> 6.31),
-// together with the non-temporal hints above.  mk_adamw_chunk() tells the host which slice size its chunk table must use.
+// together with the hinted gradient loads above.  mk_adamw_chunk() tells the host which slice size its chunk table must use.
 #ifndef MK_ADAMW_CHUNK_ELEMS
 #define MK_ADAMW_CHUNK_ELEMS 4096
 #endif
