@@ -357,7 +357,8 @@ MK_DEV void adam_store4(float* p, const float (&o)[4]) { VecIO<float>::store(p, 
 // stream; hinted stores of the 16-bit parameter copy added +0.3 % in the harness and are NOT used: with them in the per-slice
 // kernel (whose output an all-gather stages through the copy engine right behind it) the retired runtime's world-2 test came out
 // with one stale ZeRO-1 slice in 3 of 10 full-suite runs beside a busy second stream, and in 0 of 5 without them
-// (profiles/r06_dw_side_stream.txt "World 2") -- a store nobody must read late is not worth one somebody reads early.
+// (profiles/r06_dw_side_stream.txt "World 2"; suggestive only -- an isolated probe does not reproduce it -- but 0.3 % is not
+// worth the question).
 // (All four fp32 streams non-temporal measured 4.0 TB/s in rounds 1 and 3.)
 typedef unsigned int adam_u32x2 __attribute__((ext_vector_type(2)));
 typedef float adam_f32x4 __attribute__((ext_vector_type(4)));
