@@ -178,3 +178,15 @@ def test_grad_weight_side_stream_auto_rule_and_switches(monkeypatch):
         ops.rope_fuse_mode()
     monkeypatch.delenv("MACAW_ROPE_FUSE")
     assert ops.rope_fuse_mode() == "off"
+
+
+def test_adamw_slice_size_has_one_source():
+    """the multi-tensor AdamW's chunk table (host) and its kernel (library) must cut the tensors into the same slices: the host asks
+    the library (mk_adamw_chunk) instead of repeating the constant"""
+    from macaw_llm_amd import lib as L
+    from macaw_llm_amd.optim import FusedAdamW
+    import torch
+    chunk = int(L.load().mk_adamw_chunk())
+    assert chunk > 0 and chunk % 1024 == 0          # whole trips of 256 threads x 4 elements
+    opt = FusedAdamW([torch.nn.Parameter(torch.zeros(8))], lr=1e-3)
+    assert opt._CHUNK == chunk
